@@ -1,0 +1,78 @@
+"""ctypes binding of csrc/librdf_hip.so (the C ABI declared in include/rdf_hip.h).
+
+This is the only place the shared library is opened.  There is no CPU fallback: a missing
+library, or a machine without a HIP device, raises.
+"""
+import ctypes
+import os
+
+from . import _build
+
+_c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/rdf_hip.h declares
+SIGNATURES = {
+    "rdf_eval_forest": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int,
+                                 _c_void_p, _c_int, _c_void_p, _c_int, _c_float, _c_void_p]),
+    "rdf_eval_tree": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p,
+                               _c_void_p]),
+    "rdf_composite": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                               _c_void_p]),
+    "rdf_forest_packed_bytes": (_c_size_t, [_c_int, _c_int]),
+    "rdf_forest_pack": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "rdf_eval_forest_packed": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
+                                        _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
+    "rdf_eval_forest_stats": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int,
+                                       _c_void_p, _c_int, _c_void_p, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "rdf_fill_u16": (_c_int, [_c_void_p, _c_size_t, ctypes.c_uint16, _c_void_p]),
+    "rdf_debug_floor_i32": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "rdf_debug_div_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "rdf_set_lds_budget_bytes": (None, [_c_int]),
+    "rdf_set_block_threads": (None, [_c_int]),
+    "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),
+    "rdf_event_record": (_c_int, [_c_void_p, _c_void_p]),
+    "rdf_event_synchronize": (_c_int, [_c_void_p]),
+    "rdf_event_elapsed_ms": (_c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_c_float)]),
+    "rdf_event_destroy": (_c_int, [_c_void_p]),
+    "rdf_stream_synchronize": (_c_int, [_c_void_p]),
+    "rdf_abi_version": (_c_int, []),
+    "rdf_error_string": (ctypes.c_char_p, [_c_int]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class RdfError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.SO
+
+
+def load():
+    """Open librdf_hip.so and type every entry point.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RdfError(f"{path} is missing: build it first (python __graft_entry__.py build, "
+                       "or python 3d-beats_amd/_build.py). There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rdf_abi_version() != ABI_VERSION:
+        raise RdfError(f"librdf_hip.so ABI {lib.rdf_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(lib, code, what):
+    if code != 0:
+        msg = lib.rdf_error_string(int(code))
+        msg = msg.decode() if isinstance(msg, bytes) else str(msg)
+        raise RdfError(f"{what} failed: {msg} (code {code})")

@@ -1,0 +1,271 @@
+"""Host side of the RDF inference path: the reference's `decision_tree.py` surface for inference.
+
+Mirrors, name for name, the classes callers of /root/reference/src/decision_tree.py use on the
+inference path (run_live_layered.py:54-58,126; 3d_bz.py:76-110,389-437; run_live.py:123-124;
+test_on_saved_model.py:54-56):
+
+    DecisionTree(max_depth, num_classes), DecisionTree.get_config           decision_tree.py:124-144
+    DecisionForest(num_trees, max_depth, num_classes), DecisionForest.load  decision_tree.py:146-168
+    LayeredDecisionForest.load / .run and its public attributes             decision_tree.py:171-264
+    DecisionTreeEvaluator.get_labels / .get_labels_forest /
+        .make_composite_labels_image                                        decision_tree.py:267-347
+
+Kernels are reached through the C ABI of librdf_hip.so (include/rdf_hip.h); launch geometry is the
+library's business.  The dataset/training half of the reference module is out of scope.
+"""
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, device_ptr, get_runtime
+from .engine.buffer import GpuBuffer
+from .util import MAX_UINT16, sizeof_fmt  # noqa: F401  (re-exported like the reference module)
+
+_PIX_LIMIT = (1 << 31) - 1  # one C-ABI call addresses < 2^31 depth pixels (RDF_ERR_TOO_LARGE)
+
+
+class DecisionTree:
+    def __init__(self, max_depth, num_classes):
+        self.max_depth = max_depth
+        self.num_classes = num_classes
+        self.TOTAL_TREE_NODES, self.MAX_LEAF_NODES, self.TREE_NODE_ELS = DecisionTree.get_config(max_depth, num_classes)
+        # tightly packed level-order binary tree, all-zero = untrained
+        self.tree_out_cu = DeviceArray((self.TOTAL_TREE_NODES, self.TREE_NODE_ELS), np.float32)
+        self.tree_out_cu.fill(np.float32(0.))
+
+    @staticmethod
+    def get_config(max_depth, num_classes):
+        total_tree_nodes = (2 ** max_depth) - 1     # nodes of a complete tree
+        max_leaf_nodes = 2 ** max_depth             # children of the deepest level
+        tree_node_els = 7 + (num_classes * 2)       # ux,uy,vx,vy,thresh,l_next,r_next,l_pdf[C],r_pdf[C]
+        return (total_tree_nodes, max_leaf_nodes, tree_node_els)
+
+
+class DecisionForest:
+    @staticmethod
+    def load(model_filename):
+        forest_cpu = np.load(model_filename)
+        assert forest_cpu.ndim == 3, "forest .npy must be [trees, 2^D-1, 7+2C]"
+        num_trees = forest_cpu.shape[0]
+        tree_depth = int(np.log2(forest_cpu.shape[1] + 1))
+        num_classes = (forest_cpu.shape[2] - 7) // 2
+        f = DecisionForest(num_trees, tree_depth, num_classes)
+        assert forest_cpu.shape == f.forest_cu.shape, \
+            f"{model_filename}: shape {forest_cpu.shape} is not a complete depth-{tree_depth} forest"
+        f.forest_cu.set(np.ascontiguousarray(forest_cpu, dtype=np.float32))
+        return f
+
+    @staticmethod
+    def from_numpy(forest_cpu):
+        """Convenience (not in the reference): build from an in-memory [T, 2^D-1, 7+2C] float32 array."""
+        forest_cpu = np.ascontiguousarray(forest_cpu, dtype=np.float32)
+        T, n, e = forest_cpu.shape
+        f = DecisionForest(T, int(np.log2(n + 1)), (e - 7) // 2)
+        assert forest_cpu.shape == f.forest_cu.shape
+        f.forest_cu.set(forest_cpu)
+        return f
+
+    def __init__(self, num_trees, max_depth, num_classes):
+        self.num_trees = num_trees
+        self.max_depth = max_depth
+        self.num_classes = num_classes
+        self.TOTAL_TREE_NODES, self.MAX_LEAF_NODES, self.TREE_NODE_ELS = DecisionTree.get_config(max_depth, num_classes)
+        self.forest_cu = DeviceArray((self.num_trees, self.TOTAL_TREE_NODES, self.TREE_NODE_ELS), np.float32)
+        self.forest_cu.fill(np.float32(0.))
+        self._packed = {}  # scale_factor -> (forest_cu identity, version, DeviceArray)
+
+    def packed(self, scale_factor=1.):
+        """32-byte-record table for `scale_factor`, rebuilt when forest_cu has been written since.
+
+        The reference has no such step (its load is the upload at decision_tree.py:148-158); this is
+        the load-time repack described in include/rdf_hip.h.  Returns None for an empty forest."""
+        s = float(np.float32(scale_factor))
+        key = (id(self.forest_cu), self.forest_cu.version)
+        hit = self._packed.get(s)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        rt = get_runtime()
+        lib = rt.lib
+        nbytes = int(lib.rdf_forest_packed_bytes(int(self.num_trees), int(self.max_depth)))
+        if nbytes == 0:
+            return None
+        buf = hit[1] if (hit is not None and hit[1].nbytes == nbytes) else DeviceArray((nbytes,), np.uint8)
+        _lib.check(lib, lib.rdf_forest_pack(device_ptr(self.forest_cu), int(self.num_trees), int(self.max_depth),
+                                            int(self.num_classes), s, buf.ptr, rt.stream()), "rdf_forest_pack")
+        self._packed[s] = (key, buf)
+        return buf
+
+
+class LayeredDecisionForest:
+    """Stack of forests evaluated in order, later layers optionally filtered on an earlier layer's
+    labels, merged by a `conditions` table (decision_tree.py:171-264).  Owns its device buffers."""
+
+    @staticmethod
+    def load(config_filename, depth_dims, labels_reduce=1):
+        with open(config_filename) as fh:
+            cfg = json.loads(fh.read())
+        # models are loaded 1-by-1 from paths relative to the config file
+        cfg['root'] = os.path.dirname(os.path.abspath(config_filename))
+        return LayeredDecisionForest(cfg, depth_dims, labels_reduce)
+
+    def __init__(self, cfg, depth_dims, labels_reduce):
+        self.eval = DecisionTreeEvaluator()
+
+        self.depth_dims = tuple(depth_dims)  # y,x !!
+        self.labels_reduce = labels_reduce
+        self.labels_dims = (depth_dims[0] // labels_reduce, depth_dims[1] // labels_reduce)
+
+        self.m = []
+        for l in cfg['layers']:
+            m = l['model']
+            if not isinstance(m, DecisionForest):
+                m = DecisionForest.load(os.path.join(cfg.get('root', ''), m))
+            # the reference's test is effectively `'filter_model' in l` (decision_tree.py:192)
+            if 'filter_model' in l:
+                filter_model = l['filter_model']
+                filter_model_class = l['filter_model_class']
+            else:
+                filter_model = None
+                filter_model_class = None
+            self.m.append((m, filter_model, filter_model_class))
+
+        self.num_models = len(self.m)
+        for i, (_, fm, _) in enumerate(self.m):
+            assert fm is None or 0 <= fm < self.num_models, f"layer {i}: filter_model {fm} out of range"
+
+        self.label_images = [GpuBuffer(self.labels_dims, dtype=np.uint16) for _ in range(self.num_models)]
+
+        # device table of the per-layer label image addresses (decision_tree.py:205-207)
+        self.labels_images_ptrs_cu = GpuBuffer((self.num_models,), dtype=np.int64)
+        label_images_ptrs = np.array([device_ptr(i) for i in self.label_images], dtype=np.int64)
+        self.labels_images_ptrs_cu.cu().set(label_images_ptrs)
+
+        # conditions rows: (0, PIXEL_ID) or (1, NEXT_IMG_CONDITION_OFFSET); see decision_tree.py:209-220
+        labels_conditions = np.array(cfg['conditions'], dtype=np.int32)
+        assert labels_conditions.ndim == 2 and labels_conditions.shape[1] == 2
+        self.labels_conditions_cu = GpuBuffer(labels_conditions.shape, dtype=np.int32)
+        self.labels_conditions_cu.cu().set(labels_conditions)
+        self.num_layered_classes = int(max([c[1] for c in filter(lambda c: c[0] == 0, labels_conditions)]))
+
+        label_colors = np.array(cfg['label_colors'], dtype=np.uint8)
+        assert label_colors.shape == (self.num_layered_classes, 4)
+        self.label_colors = GpuBuffer(label_colors.shape, dtype=np.uint8)
+        self.label_colors.cu().set(label_colors)
+
+    def run(self, depth_image, labels_image, scale_factor=1.):
+        labels_image.cu().fill(MAX_UINT16)
+        for i in self.label_images:
+            i.cu().fill(MAX_UINT16)
+
+        # first dim: image id. only one image!
+        depth_img_dims = (1,) + self.depth_dims
+        label_img_dims = (1,) + self.labels_dims
+
+        for i in range(self.num_models):
+            m, filter_model, filter_model_class = self.m[i]
+            single_labels_image = self.label_images[i]
+            self.eval.get_labels_forest(
+                m,
+                depth_image.cu().reshape(depth_img_dims),
+                single_labels_image.cu().reshape(label_img_dims),
+                labels_reduce=self.labels_reduce,
+                filter_images=self.label_images[filter_model].cu().reshape(label_img_dims) if (filter_model is not None) else None,
+                filter_images_class=filter_model_class,
+                scale_factor=scale_factor)
+
+        self.eval.make_composite_labels_image(
+            self.labels_images_ptrs_cu.cu(),
+            self.labels_dims[1],
+            self.labels_dims[0],
+            self.labels_conditions_cu.cu(),
+            labels_image.cu().reshape(label_img_dims))
+
+
+class DecisionTreeEvaluator:
+    def __init__(self, use_packed=True):
+        self._rt = get_runtime()
+        self._lib = self._rt.lib
+        self.use_packed = use_packed
+        # pixels whose composite walk was invalid (the reference device-asserts, tree_eval.cu:246-247)
+        self._composite_bad = DeviceArray((1,), np.int32).fill(0)
+
+    # -- single tree: evaluate_image_using_tree ------------------------------------------------
+    def get_labels(self, tree, depth_images_in, labels_out):
+        num_images, dim_y, dim_x = depth_images_in.shape
+        assert tuple(labels_out.shape) == (num_images, dim_y, dim_x)
+        lib, st = self._lib, self._rt.stream()
+        for i0, n in _image_chunks(num_images, dim_y * dim_x):
+            _lib.check(lib, lib.rdf_eval_tree(
+                _at(depth_images_in, i0, dim_y * dim_x * 2), n, dim_x, dim_y,
+                device_ptr(tree.tree_out_cu), int(tree.max_depth), int(tree.num_classes),
+                _at(labels_out, i0, dim_y * dim_x * 2), st), "rdf_eval_tree")
+        _touch(labels_out)
+
+    # -- forest: evaluate_image_using_forest ---------------------------------------------------
+    def get_labels_forest(self, forest, depth_images_in, labels_out, labels_reduce=1, filter_images=None,
+                          filter_images_class=None, scale_factor=1.):
+        num_images, dim_y, dim_x = depth_images_in.shape
+
+        assert tuple(labels_out.shape) == (num_images, dim_y // labels_reduce, dim_x // labels_reduce)
+
+        if filter_images is not None:
+            assert filter_images_class is not None
+            assert tuple(filter_images.shape) == tuple(labels_out.shape)
+
+        lib, st = self._lib, self._rt.stream()
+        filter_class = int(filter_images_class) if filter_images is not None else -1
+        lpix = (dim_y // labels_reduce) * (dim_x // labels_reduce)
+        packed = forest.packed(scale_factor) if (self.use_packed and hasattr(forest, "packed")) else None
+        for i0, n in _image_chunks(num_images, dim_y * dim_x):
+            d = _at(depth_images_in, i0, dim_y * dim_x * 2)
+            o = _at(labels_out, i0, lpix * 2)
+            f = _at(filter_images, i0, lpix * 2) if filter_images is not None else None
+            if packed is not None:
+                rc = lib.rdf_eval_forest_packed(d, n, dim_x, dim_y, packed.ptr, device_ptr(forest.forest_cu),
+                                                int(forest.num_trees), int(forest.max_depth), int(forest.num_classes),
+                                                f, filter_class, o, int(labels_reduce), st)
+                _lib.check(lib, rc, "rdf_eval_forest_packed")
+            else:
+                rc = lib.rdf_eval_forest(d, n, dim_x, dim_y, device_ptr(forest.forest_cu),
+                                         int(forest.num_trees), int(forest.max_depth), int(forest.num_classes),
+                                         f, filter_class, o, int(labels_reduce), float(scale_factor), st)
+                _lib.check(lib, rc, "rdf_eval_forest")
+        _touch(labels_out)
+
+    evaluate = get_labels_forest  # the name BASELINE.json's north_star uses; not in the reference
+
+    # -- composite: make_composite_labels_image ------------------------------------------------
+    def make_composite_labels_image(self, images, dim_x, dim_y, labels_decision_tree, composite_image):
+        lib = self._lib
+        n_cond = int(labels_decision_tree.shape[0])
+        rc = lib.rdf_composite(device_ptr(images), int(images.shape[0]), int(dim_x), int(dim_y),
+                               device_ptr(labels_decision_tree), n_cond, device_ptr(composite_image),
+                               self._composite_bad.ptr, self._rt.stream())
+        _lib.check(lib, rc, "rdf_composite")
+        _touch(composite_image)
+
+    def composite_bad_pixels(self, reset=True):
+        """Pixels (since the last reset) whose composite walk left the conditions table.  Synchronises."""
+        n = int(self._composite_bad.get()[0])
+        if reset and n:
+            self._composite_bad.fill(0)
+        return n
+
+
+def _image_chunks(num_images, pix_per_image):
+    """Split a batch so that one C-ABI call addresses < 2^31 depth pixels."""
+    if num_images <= 0 or pix_per_image <= 0:
+        return [(0, max(int(num_images), 0))]
+    per = max(1, _PIX_LIMIT // int(pix_per_image))
+    return [(i, min(per, num_images - i)) for i in range(0, num_images, per)]
+
+
+def _at(arr, first_image, bytes_per_image):
+    return device_ptr(arr) + int(first_image) * int(bytes_per_image)
+
+
+def _touch(arr):
+    if isinstance(arr, DeviceArray):
+        arr.mark_dirty()

@@ -1,0 +1,126 @@
+/*
+ * rdf_hip.h -- C ABI of librdf_hip.so: per-pixel randomized-decision-forest inference on
+ * MI355X (gfx950).  Drop-in boundary for the three kernels of 3d-beats' tree_eval.cu; a host
+ * language binds these symbols where the reference binds PyCUDA's
+ * `SourceModule.get_function(...)` callables (src/decision_tree.py:269-272,
+ * src/cuda/py_nvcc_utils.py:25-37).
+ *
+ * Conventions
+ *   - every pointer is caller-owned DEVICE memory unless stated; the library allocates nothing
+ *     and frees nothing (same ownership as the reference: forest_cu / label buffers belong to
+ *     the caller, src/decision_tree.py:167, 203-207);
+ *   - launches are asynchronous on `stream` (a hipStream_t; NULL = the default stream), as the
+ *     reference's launches are on the CUDA default stream;
+ *   - return value: 0 on success, a negative RDF_ERR_* for rejected arguments, or a positive
+ *     hipError_t reported by the HIP runtime.  rdf_error_string() names either kind;
+ *   - pixels the reference kernels `return` early on are never written ("untouched" rule).
+ */
+#ifndef RDF_HIP_H
+#define RDF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDF_ABI_VERSION 1
+
+#define RDF_OK 0
+#define RDF_ERR_BAD_ARG (-1)     /* negative size, labels_reduce < 1, max_depth outside [0,30] ... */
+#define RDF_ERR_NULL_PTR (-2)    /* a required pointer is NULL */
+#define RDF_ERR_TOO_LARGE (-3)   /* one call addresses >= 2^31 depth pixels; split the batch */
+#define RDF_ERR_NO_DEVICE (-4)   /* no HIP device / not a gfx950 code object */
+
+/*
+ * Forest evaluation.  Replaces `evaluate_image_using_forest`
+ * (src/cuda/tree_eval.cu:24-137; launched from src/decision_tree.py:298-330).
+ *   depth       uint16 [n_img][dim_y][dim_x]; 0 and 65535 mean "no pixel"
+ *   forest      float32 [n_trees][2^max_depth - 1][7 + 2*n_classes], the reference's .npy layout
+ *   filter      uint16 [n_img][dim_y/r][dim_x/r], or NULL; used only when filter_class != -1
+ *   labels_out  uint16 [n_img][dim_y/r][dim_x/r]
+ * Per-tree leaf PDFs are summed in tree order 0..n_trees-1 in fp32 from +0.0f.
+ */
+int rdf_eval_forest(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                    const float *forest, int n_trees, int max_depth, int n_classes,
+                    const uint16_t *filter, int filter_class,
+                    uint16_t *labels_out, int labels_reduce, float scale_factor, void *stream);
+
+/*
+ * Single-tree evaluation.  Replaces `evaluate_image_using_tree`
+ * (src/cuda/tree_eval.cu:140-212; launched from src/decision_tree.py:277-294).
+ * No filter, labels_reduce 1, scale 1; a walk that reaches no leaf leaves the pixel untouched.
+ */
+int rdf_eval_tree(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                  const float *tree, int max_depth, int n_classes,
+                  uint16_t *labels_out, void *stream);
+
+/*
+ * Composite label image.  Replaces `make_composite_labels_image`
+ * (src/cuda/tree_eval.cu:214-248; launched from src/decision_tree.py:333-347).
+ *   label_images  DEVICE array of n_images device pointers to uint16 [dim_y][dim_x]
+ *                 (the int64 pointer table of src/decision_tree.py:205-207)
+ *   cond          int32 [n_cond][2] = (type, value) rows (src/decision_tree.py:209-223)
+ *   bad_count     optional device int32, incremented once per pixel whose walk leaves the table
+ *                 or falls off the last image (the reference device-asserts there, :246-247);
+ *                 such pixels are left untouched.  May be NULL.
+ */
+int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, int dim_y,
+                  const int32_t *cond, int n_cond, uint16_t *out, int32_t *bad_count, void *stream);
+
+/*
+ * Load-time repack of a forest into 32-byte node records {s*ux, s*uy, s*vx, s*vy, thresh,
+ * child flags}.  The reference has no counterpart: its "load" is the plain upload at
+ * src/decision_tree.py:148-158.  The packed table depends on scale_factor and must be rebuilt
+ * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes.
+ */
+size_t rdf_forest_packed_bytes(int n_trees, int max_depth);
+int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
+                    float scale_factor, void *packed, void *stream);
+
+/* rdf_eval_forest on a packed table; `forest` (original layout) is still read for leaf PDFs. */
+int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                           const void *packed, const float *forest,
+                           int n_trees, int max_depth, int n_classes,
+                           const uint16_t *filter, int filter_class,
+                           uint16_t *labels_out, int labels_reduce, void *stream);
+
+/*
+ * Visit counters for the roofline figure: same walk as rdf_eval_forest, labels_out
+ * written identically; stats (device uint64[3]) += {evaluated label-pixels, node records read,
+ * leaves reached}.
+ */
+int rdf_eval_forest_stats(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                          const float *forest, int n_trees, int max_depth, int n_classes,
+                          const uint16_t *filter, int filter_class,
+                          uint16_t *labels_out, int labels_reduce, float scale_factor,
+                          unsigned long long *stats, void *stream);
+
+/* GPUArray.fill(65535) of src/decision_tree.py:237-240 for uint16 buffers. */
+int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
+
+/* Test hook: out[i] = __float2int_rd(in[i]) as the kernels compute it (floor, saturate, NaN -> 0). */
+int rdf_debug_floor_i32(const float *in, int32_t *out, size_t n, void *stream);
+/* Test hook: out[i] = num[i] / den[i] as the kernels compute it (IEEE fp32 divide). */
+int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, void *stream);
+
+/* Tuning knobs (process-wide; 0 restores the default).  Not part of the reference surface. */
+void rdf_set_lds_budget_bytes(int bytes);
+void rdf_set_block_threads(int threads); /* 256, 512 or 1024 */
+
+/* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
+int rdf_event_create(void **event);
+int rdf_event_record(void *event, void *stream);
+int rdf_event_synchronize(void *event);
+int rdf_event_elapsed_ms(void *start, void *stop, float *ms);
+int rdf_event_destroy(void *event);
+int rdf_stream_synchronize(void *stream);
+
+int rdf_abi_version(void);
+const char *rdf_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDF_HIP_H */

@@ -1,0 +1,101 @@
+"""Host-memory stand-in for the package's HipRuntime -- TEST DOUBLE, lives under tests/ only.
+
+It lets the host logic of 3d-beats_amd/decision_tree.py (shape checks, layer wiring, pack caching,
+batch chunking, the distributed driver) run in a container without a GPU: "device" memory is numpy
+memory and the C-ABI entry points are answered by the CPU oracle on those host pointers.  Nothing
+in the shipped package imports this file.
+"""
+import ctypes
+
+import numpy as np
+
+from oracle import rdf_oracle
+
+
+class _OracleLib:
+    """Same entry-point names and argument order as include/rdf_hip.h, served by oracle/rdf_oracle.c."""
+
+    def __init__(self):
+        self._o = rdf_oracle.lib()
+        self.calls = []
+        self._packed_scale = {}
+
+    def rdf_eval_forest(self, depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, stream):
+        self.calls.append(("rdf_eval_forest", n_img, dim_x, dim_y, T, D, C, fcls, r, float(s)))
+        rc = self._o.rdf_oracle_eval_forest(depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, None, 0)
+        return 0 if rc == 0 else -1
+
+    def rdf_eval_forest_stats(self, depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, stats, stream):
+        self.calls.append(("rdf_eval_forest_stats", n_img, dim_x, dim_y, T, D, C, fcls, r, float(s)))
+        rc = self._o.rdf_oracle_eval_forest(depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, stats, 0)
+        return 0 if rc == 0 else -1
+
+    def rdf_eval_tree(self, depth, n_img, dim_x, dim_y, tree, D, C, out, stream):
+        self.calls.append(("rdf_eval_tree", n_img, dim_x, dim_y, D, C))
+        rc = self._o.rdf_oracle_eval_tree(depth, n_img, dim_x, dim_y, tree, D, C, out, 0)
+        return 0 if rc == 0 else -1
+
+    def rdf_forest_packed_bytes(self, T, D):
+        return T * ((1 << D) - 1) * 32
+
+    def rdf_forest_pack(self, forest, T, D, C, s, packed, stream):
+        self.calls.append(("rdf_forest_pack", T, D, C, float(s)))
+        self._packed_scale[int(packed)] = float(s)
+        return 0
+
+    def rdf_eval_forest_packed(self, depth, n_img, dim_x, dim_y, packed, forest, T, D, C, filt, fcls, out, r, stream):
+        s = self._packed_scale[int(packed)]
+        self.calls.append(("rdf_eval_forest_packed", n_img, dim_x, dim_y, T, D, C, fcls, r, s))
+        rc = self._o.rdf_oracle_eval_forest(depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, None, 0)
+        return 0 if rc == 0 else -1
+
+    def rdf_composite(self, images, n_images, dim_x, dim_y, cond, n_cond, out, bad, stream):
+        self.calls.append(("rdf_composite", n_images, dim_x, dim_y, n_cond))
+        nb = ctypes.c_int64(0)
+        rc = self._o.rdf_oracle_composite(images, n_images, dim_x, dim_y, cond, n_cond, out, ctypes.byref(nb))
+        if bad:
+            ctypes.cast(bad, ctypes.POINTER(ctypes.c_int32))[0] += int(nb.value)
+        return 0 if rc == 0 else -1
+
+    def rdf_fill_u16(self, dst, n, value, stream):
+        self.calls.append(("rdf_fill_u16", int(n), int(value)))
+        arr = (ctypes.c_uint16 * int(n)).from_address(int(dst))
+        np.frombuffer(arr, dtype=np.uint16)[:] = value
+        return 0
+
+    def rdf_stream_synchronize(self, stream):
+        return 0
+
+    def rdf_error_string(self, code):
+        return b"fake runtime error"
+
+
+class HostRuntime:
+    name = "host-test-double"
+
+    def __init__(self):
+        self.lib = _OracleLib()
+
+    def alloc(self, nbytes):
+        return np.zeros(max(int(nbytes), 1), dtype=np.uint8)
+
+    def ptr(self, handle):
+        return int(handle.ctypes.data)
+
+    def h2d(self, handle, offset, host_u8):
+        handle[offset:offset + host_u8.size] = host_u8
+
+    def d2h(self, handle, offset, nbytes):
+        return handle[offset:offset + nbytes].copy()
+
+    def fill_bytes(self, handle, offset, nbytes, pattern_u8):
+        if pattern_u8.size == 2 and nbytes % 2 == 0:
+            self.lib.rdf_fill_u16(self.ptr(handle) + offset, nbytes // 2, int(pattern_u8.view(np.uint16)[0]), 0)
+        else:
+            handle[offset:offset + nbytes] = np.tile(pattern_u8, nbytes // pattern_u8.size)
+
+    def stream(self):
+        return 0
+
+    def synchronize(self):
+        pass
