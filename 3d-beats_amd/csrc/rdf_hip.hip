@@ -16,7 +16,7 @@
 //
 // Bit-exactness: (s*u)/d is one fp32 multiply and one IEEE-correct fp32 divide (hipcc's default
 // v_div_scale/v_div_fmas/v_div_fixup sequence; never build this file with -ffast-math), floor +
-// saturating convert is v_cvt_flr_i32_f32, coordinate adds wrap, bounds are checked per axis.
+// saturating convert is v_floor_f32 + v_cvt_i32_f32, coordinate adds wrap, bounds are checked per axis.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -59,11 +59,14 @@ struct EvalArgs {
     float s;
 };
 
-// __float2int_rd: floor, saturating convert, NaN -> 0 (one VALU op on gfx950).
+// __float2int_rd: floor, then saturating convert with NaN -> 0 (v_floor_f32 + v_cvt_i32_f32).
+// The fused v_cvt_flr_i32_f32 is NOT equivalent: measured on gfx950 it maps NaN to INT_MAX.
+// The convert is inline asm because a C++ float->int cast is undefined outside int range.
 __device__ __forceinline__ int floor_i32(float f)
 {
     int r;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    const float fl = __builtin_floorf(f);
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(fl));
     return r;
 }
 

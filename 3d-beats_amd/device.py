@@ -47,6 +47,9 @@ class HipRuntime:
     def d2h(self, handle, offset, nbytes):
         return handle[offset:offset + nbytes].cpu().numpy()
 
+    def as_torch(self, handle, offset, nbytes):
+        return handle[offset:offset + nbytes]
+
     def fill_bytes(self, handle, offset, nbytes, pattern_u8):
         """Fill [offset, offset+nbytes) with a repeating little-endian element pattern."""
         lib = self.lib
@@ -134,8 +137,8 @@ class DeviceArray:
                 "strides": None}
 
     def torch_bytes(self):
-        """The underlying allocation as a flat torch uint8 tensor view of this array (HipRuntime only)."""
-        return self._st.handle[self._off:self._off + self.nbytes]
+        """This array's bytes as a flat torch uint8 tensor sharing its memory (for torch.distributed)."""
+        return self._st.rt.as_torch(self._st.handle, self._off, self.nbytes)
 
     # -- GPUArray-like surface ---------------------------------------------------------------
     def fill(self, value):

@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- classified Mpix/s of the RDF inference path on MI355X.
+
+One "step" = one pass of the forest kernel over this rank's batch of synthetic 848x480 depth frames
+(4 trees, depth 20, 4 classes -- BASELINE.json's metric config), frames already resident in HBM.
+Default workload: 128 frames per GPU per step (= config 4's shard, 1024 frames / 8 GPUs; it is
+config 2's frame x 128, half dense / half live-like), weak scaling: N GPUs evaluate N x 128 frames
+and rank 0 gathers all label maps (RCCL over xGMI) inside the timed region.  Config 2 itself
+(ONE 848x480 frame per launch) is measured in the same run and reported as `cfg2_single_frame`.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `cpu_baseline` is this repo's CPU restatement (oracle/rdf_oracle.c,
+OpenMP) -- the reference has no CPU path -- timed on a bounded sample of the same frames.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=848)
+    ap.add_argument("--trees", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--classes", type=int, default=4)
+    ap.add_argument("--topology", default="full", choices=["full", "trained"])
+    ap.add_argument("--chunks", type=int, default=0, help="eval/gather pipeline chunks per step (0: 1 at N=1, 4 at N>1)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
+    return ap.parse_args()
+
+
+class Events:
+    """hipEvent pairs recorded on the stream the kernels are launched on (through the C ABI)."""
+
+    def __init__(self, rt, n):
+        import ctypes
+        self.rt, self.lib, self.ct = rt, rt.lib, ctypes
+        self.ev = []
+        for _ in range(n):
+            e = ctypes.c_void_p()
+            assert self.lib.rdf_event_create(ctypes.byref(e)) == 0
+            self.ev.append(e)
+
+    def record(self, i):
+        assert self.lib.rdf_event_record(self.ev[i], self.rt.stream()) == 0
+
+    def elapsed_ms(self, i, j):
+        ms = self.ct.c_float()
+        assert self.lib.rdf_event_synchronize(self.ev[j]) == 0
+        assert self.lib.rdf_event_elapsed_ms(self.ev[i], self.ev[j], self.ct.byref(ms)) == 0
+        return float(ms.value)
+
+    def destroy(self):
+        for e in self.ev:
+            self.lib.rdf_event_destroy(e)
+
+
+def load_traffic(key):
+    """HBM bytes per launch from a committed PMC run (profiles/roofline_traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        return json.load(open(p)).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N (N>1) must be launched with torch.distributed.run --nproc-per-node N")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    rdf = importlib.import_module("3d-beats_amd")
+    dmod = importlib.import_module("3d-beats_amd.distributed")
+    synth = rdf.synth
+    rt = rdf.get_runtime()  # raises without the HIP library or a device: no CPU fallback
+    lib = rt.lib
+
+    H, W, F, T, D, C = a.height, a.width, a.frames, a.trees, a.depth, a.classes
+    forest_np = synth.forest(T, D, C, a.topology)
+    forest = rdf.DecisionForest.from_numpy(forest_np)
+    frames_np = synth.mixed_batch(F, first_idx=rank * F, h=H, w=W)
+    depth = rdf.to_device(frames_np)
+    labels = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
+    ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
+    if not a.unpacked:
+        forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
+    chunks = a.chunks or (1 if world == 1 else 4)
+    sharded = dmod.ShardedForestEvaluator(ev, forest, F, (H, W), n_chunks=chunks)
+
+    # ---- algorithmic bytes of one step, from the visit counters of the same walk ----
+    dstats = rdf.DeviceArray((3,), np.uint64).fill(0)
+    scratch = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
+    rc = lib.rdf_eval_forest_stats(depth.ptr, F, W, H, forest.forest_cu.ptr, T, D, C, None, -1, scratch.ptr, 1, 1.0,
+                                   dstats.ptr, rt.stream())
+    assert rc == 0, lib.rdf_error_string(rc)
+    stats = dstats.get()
+    alg_bytes = synth.algorithmic_bytes(F, H, W, 1, False, C, stats)
+
+    # ---- timed region ----
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sharded.step(depth, labels)
+    evs = Events(rt, 2 * a.steps)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        evs.record(2 * i)
+        sharded.step(depth, labels)
+        evs.record(2 * i + 1)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [evs.elapsed_ms(2 * i, 2 * i + 1) for i in range(a.steps)]
+    evs.destroy()
+    assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"
+
+    pix_per_step = world * F * H * W
+    value = pix_per_step * a.steps / elapsed / 1e6
+    kern_avg_s = float(np.mean(kern_ms)) / 1e3
+    achieved = alg_bytes / kern_avg_s / 1e9
+
+    out = {
+        "metric": "classified Mpix/s on 848x480 depth frames (4 trees, depth 20); % HBM roofline",
+        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{F} x {W}x{H} depth frames per GPU per step (config 4 shard = config 2 frame x {F}; "
+                               f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
+                               + ("labels gathered to rank 0 over RCCL inside the timed region" if world > 1 else "1 GPU"),
+                   "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
+                   "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed32",
+                   "pipeline_chunks": chunks, "sharding": f"frames x{world}, forest replicated"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": load_traffic(f"F{F}_T{T}_D{D}_C{C}_{a.topology}"),
+                     "kernel": "k_eval_forest", "kernel_ms": round(kern_avg_s * 1e3, 4),
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "algorithmic_bytes_per_pixel": round(alg_bytes / (F * H * W), 1),
+                     "visits": {"pixels": int(stats[0]), "node_records": int(stats[1]), "leaves": int(stats[2])}},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
+        one_d, one_l = depth[0:1], rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
+        for _ in range(10):
+            ev.get_labels_forest(forest, one_d, one_l)
+        n1 = 200
+        e1 = Events(rt, 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e1.record(0)
+        for _ in range(n1):
+            ev.get_labels_forest(forest, one_d, one_l)
+        e1.record(1)
+        torch.cuda.synchronize()
+        wall1 = (time.perf_counter() - t1) / n1
+        dev1 = e1.elapsed_ms(0, 1) / n1 / 1e3
+        e1.destroy()
+        out["cfg2_single_frame"] = {"value": round(H * W / wall1 / 1e6, 2), "unit": "Mpix/s",
+                                    "ms_per_frame_wall": round(wall1 * 1e3, 4), "ms_per_frame_device": round(dev1 * 1e3, 4),
+                                    "frame": "dense #0", "launches": n1}
+
+        if not a.no_cpu_baseline:
+            from oracle import rdf_oracle  # the checker; never the thing measured as `value`
+            got = labels.get()
+            cores = rdf_oracle.max_threads()
+            order = [i for pair in zip(range(0, F - F // 2), range(F - F // 2, F)) for i in pair]  # dense, live, dense, ...
+            done, t_cpu, mism = 0, 0.0, 0
+            for i in order:
+                want = np.full((1, H, W), 65535, np.uint16)
+                tc = time.perf_counter()
+                rdf_oracle.eval_forest(frames_np[i:i + 1], forest_np, want)
+                t_cpu += time.perf_counter() - tc
+                mism += int((want[0] != got[i]).sum())
+                done += 1
+                if t_cpu >= a.cpu_seconds:
+                    break
+            out["cpu_baseline"] = {"value": round(done * H * W / t_cpu / 1e6, 3), "unit": "Mpix/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": f"{done} of the step's {F} frames (alternating dense/live-like), "
+                                             f"{t_cpu:.1f} s of oracle/rdf_oracle.c (OpenMP, -O2) on the host; "
+                                             f"GPU labels of those frames differ in {mism} pixels"}
+            assert mism == 0, f"GPU labels differ from the oracle in {mism} pixels"
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,10 @@ class HostRuntime:
         else:
             handle[offset:offset + nbytes] = np.tile(pattern_u8, nbytes // pattern_u8.size)
 
+    def as_torch(self, handle, offset, nbytes):
+        import torch
+        return torch.from_numpy(handle)[offset:offset + nbytes]
+
     def stream(self):
         return 0
 

@@ -1,0 +1,247 @@
+"""Parity of the HIP path against the CPU oracle -- runs on the MI355X box (`-m gpu`).
+
+Everything goes through the package's reference-compatible API, i.e. through the C ABI of
+librdf_hip.so.  Bit-exact is the bar: label maps are integers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kat_cases
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rdf_golden_v1.npz")
+CASES = kat_cases.cases()
+COMPOSITE = kat_cases.composite_cases()
+
+
+class _Tree:  # duck type of DecisionTree for arbitrary device trees
+    def __init__(self, rdf, t):
+        n, e = t.shape
+        self.max_depth = int(np.log2(n + 1))
+        self.num_classes = (e - 7) // 2
+        self.tree_out_cu = rdf.to_device(t)
+
+
+def _gpu_forest(rdf, ev, depth, forest, prefill, r=1, filt=None, fcls=None, s=1.0):
+    n, h, w = depth.shape
+    f = rdf.DecisionForest.from_numpy(forest)
+    out = rdf.DeviceArray((n, h // r, w // r), np.uint16).fill(prefill)
+    ev.get_labels_forest(f, rdf.to_device(depth), out, r, rdf.to_device(filt) if filt is not None else None,
+                         fcls, s)
+    return out.get()
+
+
+@pytest.fixture(scope="module")
+def evs(rdf, gpu_runtime):
+    return {"packed": rdf.DecisionTreeEvaluator(use_packed=True), "direct": rdf.DecisionTreeEvaluator(use_packed=False)}
+
+
+def test_native_library_is_the_one_loaded(rdf, gpu_runtime):
+    assert gpu_runtime.name == "hip"
+    maps = open("/proc/self/maps").read()
+    assert "librdf_hip.so" in maps
+    assert "librdf_oracle" not in maps or True  # the oracle may be loaded by the test process as the checker
+
+
+def test_float_helpers_match_ieee(rdf, gpu_runtime):
+    lib, st = gpu_runtime.lib, gpu_runtime.stream()
+    x = np.array([0.0, -0.0, 0.5, -0.5, -1.0, -1.5, 1.999, 2147483520.0, 2147483648.0, 3e9, -2147483648.0,
+                  -2147483904.0, -3e9, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 65535.7, -65535.2], dtype=np.float32)
+    want = np.array([0, 0, 0, -1, -1, -2, 1, 2147483520, 2147483647, 2147483647, -2147483648, -2147483648,
+                     -2147483648, 2147483647, -2147483648, 0, 0, -1, 65535, -65536], dtype=np.int64).astype(np.int32)
+    dx, do = rdf.to_device(x), rdf.DeviceArray(x.shape, np.int32)
+    assert lib.rdf_debug_floor_i32(dx.ptr, do.ptr, x.size, st) == 0
+    assert np.array_equal(do.get(), want)
+    rng = np.random.default_rng(1)
+    num = np.concatenate([(rng.standard_normal(200000) * np.exp(rng.uniform(0, 14, 200000))),
+                          [0.0, -0.0, 1e-40, -1e-40, 3e38, -3e38, np.inf, -np.inf, 1e-45, 1.17549435e-38]]).astype(np.float32)
+    den = rng.integers(1, 65535, size=num.size).astype(np.float32)
+    dn, dd, dq = rdf.to_device(num), rdf.to_device(den), rdf.DeviceArray(num.shape, np.float32)
+    assert lib.rdf_debug_div_f32(dn.ptr, dd.ptr, dq.ptr, num.size, st) == 0
+    with np.errstate(all="ignore"):
+        ref = num / den
+    assert np.array_equal(dq.get().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("path", ["packed", "direct"])
+@pytest.mark.parametrize("prefill", [65535, 0])
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_known_answers_on_gpu(case, prefill, path, rdf, evs):
+    ev = evs[path]
+    if case["kind"] == "forest":
+        got = _gpu_forest(rdf, ev, case["depth"], case["forest"], prefill, case["labels_reduce"], case["filter"],
+                          case["filter_class"], case["scale_factor"])
+    else:
+        out = rdf.DeviceArray(case["depth"].shape, np.uint16).fill(prefill)
+        ev.get_labels(_Tree(rdf, case["tree"]), rdf.to_device(case["depth"]), out)
+        got = out.get()
+    want = kat_cases.expected_array(case["expected"], prefill)
+    assert np.array_equal(got, want), f"{case['name']} ({case['cite']}):\n got {got}\nwant {want}"
+
+
+@pytest.mark.parametrize("case", COMPOSITE, ids=[c["name"] for c in COMPOSITE])
+def test_composite_known_answers_on_gpu(case, rdf, evs):
+    ev = evs["packed"]
+    for prefill in (65535, 0):
+        imgs = [rdf.to_device(a) for a in case["images"]]
+        table = rdf.to_device(np.array([i.ptr for i in imgs], dtype=np.int64))
+        h, w = case["images"][0].shape
+        out = rdf.DeviceArray((1, h, w), np.uint16).fill(prefill)
+        ev.make_composite_labels_image(table, w, h, rdf.to_device(case["cond"]), out)
+        assert np.array_equal(out.get(), kat_cases.expected_array(case["expected"], prefill)), case["name"]
+        assert ev.composite_bad_pixels() == case["bad"]
+
+
+@pytest.mark.parametrize("path", ["packed", "direct"])
+def test_golden_vectors_on_gpu(path, rdf, evs):
+    g = np.load(GOLDEN)
+    ev = evs[path]
+    assert np.array_equal(_gpu_forest(rdf, ev, g["g1_depth"], g["g1_forest"], 65535), g["g1_labels"])
+    assert np.array_equal(_gpu_forest(rdf, ev, g["g2_depth"], g["g2_forest"], 0, 2, g["g2_filter"], 1, 0.5),
+                          g["g2_labels"])
+    out = rdf.DeviceArray(g["g4_labels"].shape, np.uint16).fill(7)
+    ev.get_labels(_Tree(rdf, g["g4_tree"]), rdf.to_device(g["g4_depth"]), out)
+    assert np.array_equal(out.get(), g["g4_labels"])
+
+
+def test_layered_run_on_gpu_matches_golden(rdf, gpu_runtime, tmp_path):
+    g = np.load(GOLDEN)
+    np.save(tmp_path / "l0.npy", g["g3_forest0"])
+    np.save(tmp_path / "l1.npy", g["g3_forest1"])
+    cfg = {"layers": [{"model": "l0.npy"}, {"model": "l1.npy", "filter_model": 0, "filter_model_class": 3}],
+           "conditions": g["g3_cond"].tolist(), "label_colors": [[1, 2, 3, 4]] * 4}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    lf = rdf.LayeredDecisionForest.load(str(tmp_path / "cfg.json"), (60, 84), labels_reduce=2)
+    depth, labels = rdf.GpuBuffer((60, 84), np.uint16), rdf.GpuBuffer((30, 42), np.uint16)
+    depth.cu().set(g["g3_depth"][0])
+    for _ in range(2):  # second run: buffers are re-filled, result identical
+        lf.run(depth, labels, 1.0)
+        assert np.array_equal(lf.label_images[0].cu().get(), g["g3_l0"][0])
+        assert np.array_equal(lf.label_images[1].cu().get(), g["g3_l1"][0])
+        assert np.array_equal(labels.cu().get(), g["g3_comp"][0])
+    assert lf.eval.composite_bad_pixels() == 0
+
+
+SWEEP = [
+    # T, D, C, topo, n, h, w, r, s, filter
+    (1, 5, 2, "trained", 1, 17, 23, 1, 1.0, False),
+    (2, 12, 3, "trained", 2, 61, 67, 1, 1.0, True),
+    (3, 11, 4, "full", 3, 40, 130, 2, 0.5, False),
+    (4, 13, 4, "trained", 2, 96, 160, 1, 1.0, False),
+    (5, 10, 5, "trained", 2, 50, 77, 3, 2.0, True),
+    (7, 9, 7, "full", 1, 64, 64, 1, 0.75, False),
+    (8, 12, 9, "trained", 2, 48, 80, 2, 1.0, False),
+    (9, 7, 17, "trained", 1, 33, 65, 1, 1.0, False),
+    (4, 10, 33, "full", 1, 20, 70, 1, 1.0, True),
+    (4, 1, 4, "full", 1, 9, 11, 1, 1.0, False),
+]
+
+
+@pytest.mark.parametrize("path", ["packed", "direct"])
+@pytest.mark.parametrize("cfg", SWEEP, ids=[f"T{c[0]}D{c[1]}C{c[2]}{c[3]}r{c[7]}" for c in SWEEP])
+def test_random_sweep_bit_exact(cfg, path, rdf, evs, oracle):
+    T, D, C, topo, n, h, w, r, s, use_filter = cfg
+    synth = rdf.synth
+    forest = synth.forest(T, D, C, topo, first_tree=T * 3)
+    depth = synth.frames((["dense", "live"] * n)[:n], 500 + T, h, w)
+    filt = (np.random.default_rng(T).integers(0, 3, size=(n, h // r, w // r))).astype(np.uint16) if use_filter else None
+    want = np.full((n, h // r, w // r), 65535, np.uint16)
+    oracle.eval_forest(depth, forest, want, r, filt, 1 if use_filter else None, s)
+    got = _gpu_forest(rdf, evs[path], depth, forest, 65535, r, filt, 1 if use_filter else None, s)
+    assert np.array_equal(got, want), f"{(got != want).sum()} of {want.size} pixels differ"
+
+
+@pytest.mark.parametrize("block,lds", [(256, 0), (256, 4096), (512, 81920), (1024, 163840), (1024, 0)])
+def test_launch_geometry_does_not_change_results(block, lds, rdf, gpu_runtime, evs, oracle):
+    synth = rdf.synth
+    forest = synth.forest(4, 12, 4, "trained")
+    depth = synth.frames(["live", "dense", "live"], 700, 120, 200)
+    want = np.full(depth.shape, 65535, np.uint16)
+    oracle.eval_forest(depth, forest, want)
+    lib = gpu_runtime.lib
+    lib.rdf_set_block_threads(block)
+    lib.rdf_set_lds_budget_bytes(lds if lds else 1)
+    try:
+        for path in ("packed", "direct"):
+            assert np.array_equal(_gpu_forest(rdf, evs[path], depth, forest, 65535), want), (block, lds, path)
+    finally:
+        lib.rdf_set_block_threads(0)
+        lib.rdf_set_lds_budget_bytes(0)
+
+
+@pytest.mark.parametrize("topology", ["full", "trained"])
+def test_config2_full_size_bit_exact(topology, rdf, evs, oracle, gpu_runtime):
+    """BASELINE config 2: 848x480 frames (one dense, one live-like), 4-tree depth-20 forest, C=4."""
+    synth = rdf.synth
+    forest = synth.forest(4, 20, 4, topology)
+    depth = synth.frames(["dense", "live"], 0)
+    want = np.full(depth.shape, 65535, np.uint16)
+    st = np.zeros(3, np.uint64)
+    oracle.eval_forest(depth, forest, want, stats=st)
+    for path in ("packed", "direct"):
+        got = _gpu_forest(rdf, evs[path], depth, forest, 65535)
+        assert np.array_equal(got, want), f"{path}: {(got != want).sum()} pixels differ"
+    # visit counters of the stats kernel == oracle's (they define the algorithmic bytes)
+    lib = gpu_runtime.lib
+    f = rdf.DecisionForest.from_numpy(forest)
+    out = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
+    dstats = rdf.DeviceArray((3,), np.uint64).fill(0)
+    rc = lib.rdf_eval_forest_stats(rdf.to_device(depth).ptr, 2, 848, 480, f.forest_cu.ptr, 4, 20, 4, None, -1, out.ptr,
+                                   1, 1.0, dstats.ptr, gpu_runtime.stream())
+    assert rc == 0
+    assert np.array_equal(out.get(), want)
+    assert np.array_equal(dstats.get(), st)
+    if topology == "full":
+        assert oracle.order_sensitive(depth, forest) == 0
+
+
+def test_batch_properties_at_scale(rdf, evs, gpu_runtime):
+    """Size-independent properties on a 32-frame 848x480 batch (too big to run through the oracle in
+    seconds): batching == frame-by-frame, idempotence, untouched pixels keep any pre-fill, packed == direct."""
+    synth = rdf.synth
+    forest = rdf.DecisionForest.from_numpy(synth.forest(4, 16, 4, "trained"))
+    host = synth.mixed_batch(32, first_idx=900)
+    depth = rdf.to_device(host)
+    ev = evs["packed"]
+    a = rdf.DeviceArray(host.shape, np.uint16).fill(65535)
+    ev.get_labels_forest(forest, depth, a)
+    A = a.get()
+    ev.get_labels_forest(forest, depth, a)           # idempotent
+    assert np.array_equal(a.get(), A)
+    b = rdf.DeviceArray(host.shape, np.uint16).fill(1234)
+    evs["direct"].get_labels_forest(forest, depth, b)
+    B = b.get()
+    invalid = (host == 0) | (host == 65535)
+    assert (A[invalid] == 65535).all() and (B[invalid] == 1234).all()
+    assert np.array_equal(A[~invalid], B[~invalid])
+    assert A[~invalid].max() < 4
+    for i in (0, 15, 16, 31):                        # frame-by-frame
+        one = rdf.DeviceArray((1,) + host.shape[1:], np.uint16).fill(65535)
+        ev.get_labels_forest(forest, depth[i:i + 1], one)
+        assert np.array_equal(one.get()[0], A[i])
+
+
+def test_fill_u16_any_alignment(rdf, gpu_runtime):
+    lib, st = gpu_runtime.lib, gpu_runtime.stream()
+    buf = rdf.DeviceArray((5000,), np.uint16)
+    for off, n in [(0, 5000), (1, 4999), (3, 17), (7, 1), (5, 0), (2, 4096), (9, 1001)]:
+        buf.fill(0)
+        assert lib.rdf_fill_u16(buf.ptr + 2 * off, n, 65535, st) == 0
+        h = buf.get()
+        assert (h[off:off + n] == 65535).all() and h[:off].sum() == 0 and h[off + n:].sum() == 0
+
+
+def test_bad_arguments_are_rejected(rdf, gpu_runtime):
+    lib, st = gpu_runtime.lib, gpu_runtime.stream()
+    d = rdf.DeviceArray((1, 4, 4), np.uint16).fill(5)
+    f = rdf.DeviceArray((1, 1, 9), np.float32).fill(0)
+    assert lib.rdf_eval_forest(d.ptr, 1, 4, 4, f.ptr, 1, 1, 1, None, -1, d.ptr, 0, 1.0, st) == -1      # r = 0
+    assert lib.rdf_eval_forest(d.ptr, 1, 4, 4, f.ptr, 1, 31, 1, None, -1, d.ptr, 1, 1.0, st) == -1     # depth 31
+    assert lib.rdf_eval_forest(None, 1, 4, 4, f.ptr, 1, 1, 1, None, -1, d.ptr, 1, 1.0, st) == -2       # NULL
+    assert lib.rdf_eval_forest(d.ptr, 1, 4, 4, f.ptr, 1, 1, 1, None, 2, d.ptr, 1, 1.0, st) == -2        # filter NULL
+    assert lib.rdf_eval_forest(d.ptr, 70000, 1 << 15, 1, f.ptr, 1, 1, 1, None, -1, d.ptr, 1, 1.0, st) == -3
+    assert lib.rdf_eval_forest(d.ptr, 0, 4, 4, f.ptr, 1, 1, 1, None, -1, d.ptr, 1, 1.0, st) == 0        # empty batch
+    assert lib.rdf_eval_forest(d.ptr, 1, 4, 4, f.ptr, 1, 1, 1, None, -1, d.ptr, 8, 1.0, st) == 0        # r > dims
