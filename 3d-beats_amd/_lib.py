@@ -29,6 +29,7 @@ SIGNATURES = {
     "rdf_debug_div_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_set_lds_budget_bytes": (None, [_c_int]),
     "rdf_set_block_threads": (None, [_c_int]),
+    "rdf_set_scheduler": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),
     "rdf_event_record": (_c_int, [_c_void_p, _c_void_p]),
     "rdf_event_synchronize": (_c_int, [_c_void_p]),
@@ -48,7 +49,8 @@ class RdfError(RuntimeError):
 
 
 def library_path():
-    return _build.SO
+    # RDF_HIP_LIBRARY: alternate build of the same ABI (kernel timing experiments); default in-tree .so
+    return os.environ.get("RDF_HIP_LIBRARY") or _build.SO
 
 
 def load():

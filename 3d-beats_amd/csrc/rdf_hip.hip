@@ -5,14 +5,15 @@
 //   * one LANE owns one label pixel and walks kGroup trees interleaved, level-synchronously, so
 //     that kGroup node fetches and 2*kGroup depth probes are in flight per lane (the reference
 //     uses one thread per (pixel,tree), shared-memory float atomics and two block barriers);
-//   * a wave is 64 consecutive label pixels of one row: the centre-depth read, the label store
-//     and -- for smooth surfaces -- each probe are one or two 128-byte lines;
+//   * a wave is 64 consecutive label pixels of one row; a workgroup owns a 2-D tile (64 columns x
+//     4 rows per wave, rows of the waves interleaved) so that the probe neighbourhoods of its waves
+//     overlap in the CU's L1; the centre-depth read and the label store are one 128-byte line;
 //   * per-tree leaf PDFs are added in registers in tree order (canonical order, no atomics);
 //   * the top levels of every tree live in LDS as 32-byte records {s*u, s*v, thresh, flags};
 //     deeper levels are fetched from a packed 32-byte-record table (rdf_forest_pack) or, for
 //     the unpacked entry point, straight from the reference's 7+2C-float records;
-//   * tiles are dealt to workgroups through an XCD-aware bijective remap so the tiles of one
-//     frame share one XCD's L2.
+//   * tiles are handed to persistent workgroups by a device-side queue (one atomic per tile), so
+//     empty (background) tiles cost almost nothing and frames of unequal cost balance out.
 //
 // Bit-exactness: (s*u)/d is one fp32 multiply and one IEEE-correct fp32 divide (hipcc's default
 // v_div_scale/v_div_fmas/v_div_fixup sequence; never build this file with -ffast-math), floor +
@@ -23,18 +24,32 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/rdf_hip.h"
 
 namespace {
 
 constexpr int kGroup = 4;          // trees walked interleaved by one lane
+constexpr int kChunkGroups = 4;    // 64-pixel groups a wave takes per scheduler pull
 constexpr int kDefaultLdsBudget = 80 * 1024;
 constexpr uint32_t kNoPixel = 65535u;
+constexpr uint32_t kFlagLeft = 1u, kFlagRight = 2u, kFlagSlowDiv = 4u;
+constexpr int kSchedSlots = 256;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Dynamic chunk scheduler state, one slot per (device, stream) in use: {next chunk, waves finished}.
+// Zero at rest: the last wave of a launch resets its slot, so launches need no memset and replay
+// correctly from a captured hipGraph.
+__device__ unsigned int g_sched[kSchedSlots][2];
 
 struct alignas(16) NodeRec {       // 32 bytes
     float sux, suy, svx, svy;      // scale_factor * (u.x, u.y, v.x, v.y)
     float thresh;
-    uint32_t flags;                // bit0: left child continues, bit1: right child continues
+    uint32_t flags;                // kFlagLeft / kFlagRight: that child continues; kFlagSlowDiv
     uint32_t pad0, pad1;
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
@@ -46,11 +61,13 @@ struct EvalArgs {
     const uint16_t *filter;
     uint16_t *labels;
     unsigned long long *stats;
-    uint32_t total;        // label pixels in this launch
-    uint32_t n_tiles;
+    unsigned int *sched;   // scheduler slot, or nullptr for static round-robin chunks
+    uint32_t n_tiles;      // n_img * tiles_x * tiles_y
+    uint32_t tiles_x;      // ceil(Wl / 64)
+    uint32_t tiles_y;      // ceil(Hl / (waves per block * kChunkGroups))
     uint32_t per_img_l;    // Wl*Hl
     uint32_t per_img_d;    // W*H
-    int W, H, Wl, r;
+    int W, H, Wl, Hl, r;
     int T, D, C, E;
     int nodes;             // 2^D - 1
     int lds_levels;        // top levels held in LDS
@@ -70,49 +87,74 @@ __device__ __forceinline__ int floor_i32(float f)
     return r;
 }
 
+// Same result for every non-NaN input (checked on gfx950, tests/test_gpu_parity.py); one VALU op.
+__device__ __forceinline__ int floor_i32_not_nan(float f)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
 __device__ __forceinline__ int add_wrap(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
 
 // floor(x) == -1  <=>  -1 <= x < 0   (NaN: false).  tree_eval.cu:101-102 / :186-187.
 __device__ __forceinline__ uint32_t child_flags(float l, float r)
 {
-    return ((l >= -1.0f && l < 0.0f) ? 1u : 0u) | ((r >= -1.0f && r < 0.0f) ? 2u : 0u);
+    return ((l >= -1.0f && l < 0.0f) ? kFlagLeft : 0u) | ((r >= -1.0f && r < 0.0f) ? kFlagRight : 0u);
 }
 
-// XCD-aware bijective remap of a physical slot (slot % 8 = XCD group under round-robin dispatch)
-// to a logical tile, so that each XCD group owns one contiguous run of tiles.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t slot, uint32_t n)
+// The shared-reciprocal divide (see eval loop) is proven equal to the IEEE divide, in floor-to-int,
+// for every depth 1..65534 and every numerator that is +-0 or has a biased exponent in [40, 230]
+// (tools/verify_fastdiv.hip, exhaustive on gfx950).  Anything else takes the IEEE path.
+__device__ __forceinline__ bool needs_ieee_divide(float a)
 {
-    const uint32_t q = n >> 3, r = n & 7u, x = slot & 7u, o = slot >> 3;
-    const uint32_t base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return base + o;
+    const uint32_t b = __float_as_uint(a);
+    return (b << 1) != 0u && (((b >> 23) & 0xFFu) - 40u) > 190u;
+}
+
+__device__ __forceinline__ uint32_t node_flags(float sux, float suy, float svx, float svy, float l, float r)
+{
+    const bool slow = needs_ieee_divide(sux) | needs_ieee_divide(suy) | needs_ieee_divide(svx) | needs_ieee_divide(svy);
+    return child_flags(l, r) | (slow ? kFlagSlowDiv : 0u);
 }
 
 // Depth probe with per-axis bounds check, out of bounds -> 65535 (cu_utils.hpp:79-86).
-__device__ __forceinline__ float probe(const uint16_t *depth, uint32_t img_off, int x, int y, int W, int H)
+// `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets (batch < 2^31 pixels).
+__device__ __forceinline__ float probe(const char *depth_b, uint32_t img_boff, int x, int y, int W, int H)
 {
     const bool inb = (uint32_t)x < (uint32_t)W && (uint32_t)y < (uint32_t)H;
-    const uint32_t off = inb ? img_off + (uint32_t)y * (uint32_t)W + (uint32_t)x : img_off;
-    const uint32_t v = depth[off];
+    const uint32_t off = inb ? img_boff + (((uint32_t)y * (uint32_t)W + (uint32_t)x) << 1) : img_boff;
+    const uint32_t v = *reinterpret_cast<const uint16_t *>(depth_b + off);
     return inb ? (float)v : 65535.0f;
 }
 
+struct Node {
+    float sux, suy, svx, svy, thresh;
+    uint32_t flags;
+};
+
+// Node record of tree `tree` (wave-uniform) at level-order index idx, from global memory.
 template <bool PACKED>
-__device__ __forceinline__ NodeRec load_global_node(const EvalArgs &a, int tree, uint32_t idx)
+__device__ __forceinline__ Node load_global_node(const EvalArgs &a, int tree, uint32_t idx)
 {
-    NodeRec n;
+    Node n;
     if (PACKED) {
-        const NodeRec *p = a.packed + (size_t)tree * (size_t)a.nodes + idx;
-        const float4 v = *reinterpret_cast<const float4 *>(p);
-        const float2 w = *reinterpret_cast<const float2 *>(&p->thresh);
+        const char *base = reinterpret_cast<const char *>(a.packed + (size_t)tree * (size_t)a.nodes);
+        const uint32_t off = idx * 32u;
+        const float4 v = *reinterpret_cast<const float4 *>(base + off);
+#ifdef RDF_ABLATE_NODE2
+        const float2 w = {v.x * 1e-3f, __uint_as_float(3u)};   // timing experiment: one load per node
+#else
+        const float2 w = *reinterpret_cast<const float2 *>(base + off + 16u);
+#endif
         n.sux = v.x; n.suy = v.y; n.svx = v.z; n.svy = v.w;
         n.thresh = w.x; n.flags = __float_as_uint(w.y);
     } else {
         const float *p = a.forest + ((size_t)tree * (size_t)a.nodes + idx) * (size_t)a.E;
         n.sux = a.s * p[0]; n.suy = a.s * p[1]; n.svx = a.s * p[2]; n.svy = a.s * p[3];
         n.thresh = p[4];
-        n.flags = child_flags(p[5], p[6]);
+        n.flags = child_flags(p[5], p[6]) | kFlagSlowDiv;   // the unpacked path always divides IEEE
     }
-    n.pad0 = n.pad1 = 0;
     return n;
 }
 
@@ -123,143 +165,233 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
     NodeRec *lds = reinterpret_cast<NodeRec *>(lds_raw);
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int K = a.lds_levels;
     const uint32_t nodes_lds = (1u << K) - 1u;
 
     // ---- stage the top K levels of every tree (level order => the first 2^K-1 records) ----
     for (uint32_t i = tid; i < (uint32_t)a.T * nodes_lds; i += BLOCK) {
-        const uint32_t k = i / nodes_lds, n = i - k * nodes_lds;
-        lds[i] = load_global_node<PACKED>(a, (int)k, n);
+        const uint32_t k = i / nodes_lds, nn = i - k * nodes_lds;
+        NodeRec rec;
+        if (PACKED) {
+            rec = a.packed[(size_t)k * (size_t)a.nodes + nn];
+        } else {
+            const Node n = load_global_node<false>(a, (int)k, nn);
+            rec.sux = n.sux; rec.suy = n.suy; rec.svx = n.svx; rec.svy = n.svy;
+            rec.thresh = n.thresh; rec.flags = n.flags; rec.pad0 = rec.pad1 = 0;
+        }
+        lds[i] = rec;
     }
     __syncthreads();
 
     unsigned long long st_px = 0, st_lv = 0, st_lf = 0;
+    const char *depth_b = reinterpret_cast<const char *>(a.depth);
+    constexpr uint32_t kWaves = BLOCK / 64;
+    constexpr uint32_t kTileRows = kWaves * kChunkGroups;
+    const uint32_t wave = (uint32_t)tid >> 6;
+    // queue mailbox lives behind the node table in the one dynamic LDS allocation (a second,
+    // static __shared__ object could push the dynamic base off 16-byte alignment)
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(lds + (size_t)a.T * nodes_lds);
+    uint32_t static_tile = blockIdx.x;
 
-    for (uint32_t slot = blockIdx.x; slot < a.n_tiles; slot += gridDim.x) {
-        const uint32_t tile = xcd_tile(slot, a.n_tiles);
-        const uint32_t i = tile * BLOCK + tid;
-        if (i >= a.total) continue;
-
-        const uint32_t img = i / a.per_img_l;
-        const uint32_t rem = i - img * a.per_img_l;
-        const int ly = (int)(rem / (uint32_t)a.Wl);
-        const int lx = (int)(rem - (uint32_t)ly * (uint32_t)a.Wl);
-        const int x = lx * a.r, y = ly * a.r;
-        const uint32_t img_off = img * a.per_img_d;
-
-        if (a.filter_class != -1) {
-            if ((int)a.filter[i] != a.filter_class) continue;
+    for (uint32_t it = 0;; ++it) {
+        // ---- take the next tile: 64 label columns x kTileRows label rows of one image ----
+        uint32_t tile;
+        if (a.sched) {
+            if (tid == 0) s_tile[it & 1u] = atomicAdd(a.sched, 1u);
+            __syncthreads();   // one barrier per tile: the slot written next is the other one
+            tile = s_tile[it & 1u];
+        } else {
+            tile = static_tile;
+            static_tile += gridDim.x;
         }
-        const uint32_t d = a.depth[img_off + (uint32_t)y * (uint32_t)a.W + (uint32_t)x];
-        if (d == 0u || d == kNoPixel) continue;
-        const float df = (float)d;
+        if (tile >= a.n_tiles) break;
+        const uint32_t tiles_per_img = a.tiles_x * a.tiles_y;
+        const uint32_t img = tile / tiles_per_img;
+        const uint32_t trem = tile - img * tiles_per_img;
+        const uint32_t ty = trem / a.tiles_x;
+        const uint32_t tx = trem - ty * a.tiles_x;
+        const int lx = (int)(tx * 64u) + lane;
+        const uint32_t img_boff = (img * a.per_img_d) << 1;
+        const uint32_t img_loff = img * a.per_img_l;
 
-        float best = 0.0f;
-        int best_c = 0;
-        bool any_leaf = false;
+        for (int sub = 0; sub < kChunkGroups; ++sub) {
+            // rows of the workgroup's waves are interleaved: at any time they cover adjacent rows
+            const int ly = (int)(ty * kTileRows + (uint32_t)sub * kWaves + wave);
+            if (ly >= a.Hl || lx >= a.Wl) continue;
+            const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
+            const int x = lx * a.r, y = ly * a.r;
 
-        for (int c0 = 0; c0 < a.C || c0 == 0; c0 += CMAX) {
-            float pdf[CMAX];
+            if (a.filter_class != -1) {
+                if ((int)a.filter[i] != a.filter_class) continue;
+            }
+            const uint32_t d = *reinterpret_cast<const uint16_t *>(
+                depth_b + (img_boff + (((uint32_t)y * (uint32_t)a.W + (uint32_t)x) << 1)));
+            if (d == 0u || d == kNoPixel) continue;
+            const float df = (float)d;
+            // refined reciprocal shared by every divide of this pixel (fast path only)
+            const float r0 = __builtin_amdgcn_rcpf(df);
+            const float rcp = __builtin_fmaf(__builtin_fmaf(-df, r0, 1.0f), r0, r0);
+            const f2 rcp2 = {rcp, rcp};
+            const f2 ndf2 = {-df, -df};
+
+            float best = 0.0f;
+            int best_c = 0;
+            bool any_leaf = false;
+
+            for (int c0 = 0; c0 < a.C || c0 == 0; c0 += CMAX) {
+                float pdf[CMAX];
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) pdf[c] = 0.0f;
+                for (int c = 0; c < CMAX; ++c) pdf[c] = 0.0f;
 
-            for (int kb = 0; kb < a.T; kb += kGroup) {
-                uint32_t g[kGroup];
-                int leaf[kGroup];
-                bool act[kGroup];
+                for (int kb = 0; kb < a.T; kb += kGroup) {
+                    uint32_t g[kGroup];
+                    int leaf[kGroup];
+                    bool act[kGroup];
 #pragma unroll
-                for (int k = 0; k < kGroup; ++k) {
-                    g[k] = 0u;
-                    leaf[k] = -1;
-                    act[k] = (kb + k) < a.T;
-                }
+                    for (int k = 0; k < kGroup; ++k) {
+                        g[k] = 0u;
+                        leaf[k] = -1;
+                        act[k] = (kb + k) < a.T;
+                    }
 
-                for (int j = 0; j < a.D; ++j) {
-                    bool any = false;
+                    for (int j = 0; j < a.D; ++j) {
+                        bool any = false;
 #pragma unroll
-                    for (int k = 0; k < kGroup; ++k) any |= act[k];
-                    if (!__any(any)) break;
+                        for (int k = 0; k < kGroup; ++k) any |= act[k];
+                        if (!__any(any)) break;
 
-                    const uint32_t lvl = (1u << j) - 1u;
-                    NodeRec n[kGroup];
-                    if (j < K) {
+                        const uint32_t lvl = (1u << j) - 1u;
+                        Node n[kGroup];
+                        if (j < K) {
 #pragma unroll
-                        for (int k = 0; k < kGroup; ++k) {
-                            const uint32_t t = act[k] ? (uint32_t)(kb + k) : 0u;
-                            const uint32_t idx = act[k] ? lvl + g[k] : 0u;
-                            const NodeRec *p = lds + t * nodes_lds + idx;
-                            const float4 v = *reinterpret_cast<const float4 *>(p);
-                            const float2 w = *reinterpret_cast<const float2 *>(&p->thresh);
-                            n[k].sux = v.x; n[k].suy = v.y; n[k].svx = v.z; n[k].svy = v.w;
-                            n[k].thresh = w.x; n[k].flags = __float_as_uint(w.y);
+                            for (int k = 0; k < kGroup; ++k) {
+                                const uint32_t tk = (uint32_t)min(kb + k, a.T - 1);   // wave-uniform
+                                const uint32_t idx = act[k] ? lvl + g[k] : 0u;
+                                const NodeRec *p = lds + tk * nodes_lds + idx;
+                                const float4 v = *reinterpret_cast<const float4 *>(p);
+                                const float2 w = *reinterpret_cast<const float2 *>(&p->thresh);
+                                n[k].sux = v.x; n[k].suy = v.y; n[k].svx = v.z; n[k].svy = v.w;
+                                n[k].thresh = w.x; n[k].flags = __float_as_uint(w.y);
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < kGroup; ++k) {
+                                const int tk = min(kb + k, a.T - 1);
+                                const uint32_t idx = act[k] ? lvl + g[k] : 0u;
+                                n[k] = load_global_node<PACKED>(a, tk, idx);
+                            }
                         }
-                    } else {
+
+                        // ---- probe coordinates: x + floor((s*u.x)/d) ... (decision_tree_common.hpp:15-22) ----
+                        int ux[kGroup], uy[kGroup], vx[kGroup], vy[kGroup];
+                        bool slow = !PACKED;
+                        if (PACKED) {
+                            uint32_t fl = 0u;
+#pragma unroll
+                            for (int k = 0; k < kGroup; ++k) fl |= n[k].flags;
+                            slow = __any((fl & kFlagSlowDiv) != 0u);
+                        }
+                        if (slow) {
+#pragma unroll
+                            for (int k = 0; k < kGroup; ++k) {
+                                ux[k] = add_wrap(x, floor_i32(n[k].sux / df));
+                                uy[k] = add_wrap(y, floor_i32(n[k].suy / df));
+                                vx[k] = add_wrap(x, floor_i32(n[k].svx / df));
+                                vy[k] = add_wrap(y, floor_i32(n[k].svy / df));
+                            }
+                        } else {
+                            // q0 = a*rcp; rem = a - d*q0 (exact, fma); q = q0 + rem*rcp.  Packed f32 math,
+                            // two quotients per instruction.
+#pragma unroll
+                            for (int k = 0; k < kGroup; ++k) {
+                                const f2 nu = {n[k].sux, n[k].suy};
+                                const f2 nv = {n[k].svx, n[k].svy};
+                                const f2 qu0 = nu * rcp2;
+                                const f2 qv0 = nv * rcp2;
+                                const f2 ru = __builtin_elementwise_fma(ndf2, qu0, nu);
+                                const f2 rv = __builtin_elementwise_fma(ndf2, qv0, nv);
+                                const f2 qu = __builtin_elementwise_fma(ru, rcp2, qu0);
+                                const f2 qv = __builtin_elementwise_fma(rv, rcp2, qv0);
+                                ux[k] = add_wrap(x, floor_i32_not_nan(qu.x));
+                                uy[k] = add_wrap(y, floor_i32_not_nan(qu.y));
+                                vx[k] = add_wrap(x, floor_i32_not_nan(qv.x));
+                                vy[k] = add_wrap(y, floor_i32_not_nan(qv.y));
+                            }
+                        }
+
+                        float pu[kGroup], pv[kGroup];
 #pragma unroll
                         for (int k = 0; k < kGroup; ++k) {
-                            const int t = act[k] ? (kb + k) : 0;
-                            const uint32_t idx = act[k] ? lvl + g[k] : 0u;
-                            n[k] = load_global_node<PACKED>(a, t, idx);
+                            pu[k] = probe(depth_b, img_boff, ux[k], uy[k], a.W, a.H);
+#ifdef RDF_ABLATE_VPROBE
+                            pv[k] = (float)(vx[k] ^ vy[k]);   // timing experiment: no second probe
+#else
+                            pv[k] = probe(depth_b, img_boff, vx[k], vy[k], a.W, a.H);
+#endif
+#ifdef RDF_ABLATE_UPROBE
+                            pu[k] = (float)(ux[k] ^ uy[k]);   // timing experiment: no probes at all
+#endif
+                        }
+
+#pragma unroll
+                        for (int k = 0; k < kGroup; ++k) {
+                            if (act[k]) {
+                                if (STATS && c0 == 0) st_lv++;
+                                const float f = pu[k] - pv[k];
+                                const bool left = f < n[k].thresh;
+                                const bool cont = (n[k].flags & (left ? kFlagLeft : kFlagRight)) != 0u;
+                                const uint32_t side = left ? 0u : 1u;
+                                if (cont) {
+                                    g[k] = g[k] * 2u + side;
+                                } else {
+                                    leaf[k] = (int)(((lvl + g[k]) << 1) | side);
+                                    act[k] = false;
+                                }
+                            }
                         }
                     }
 
-                    float pu[kGroup], pv[kGroup];
+                    // leaf PDFs, strictly in tree order (canonical sum order)
 #pragma unroll
                     for (int k = 0; k < kGroup; ++k) {
-                        const int ux = add_wrap(x, floor_i32(n[k].sux / df));
-                        const int uy = add_wrap(y, floor_i32(n[k].suy / df));
-                        const int vx = add_wrap(x, floor_i32(n[k].svx / df));
-                        const int vy = add_wrap(y, floor_i32(n[k].svy / df));
-                        pu[k] = probe(a.depth, img_off, ux, uy, a.W, a.H);
-                        pv[k] = probe(a.depth, img_off, vx, vy, a.W, a.H);
-                    }
-
+                        if (leaf[k] >= 0) {
+                            any_leaf = true;
+                            if (STATS && c0 == 0) st_lf++;
+                            const float *pp = a.forest +
+                                ((size_t)(kb + k) * (size_t)a.nodes + (uint32_t)(leaf[k] >> 1)) * (size_t)a.E +
+                                7 + (leaf[k] & 1) * a.C + c0;
 #pragma unroll
-                    for (int k = 0; k < kGroup; ++k) {
-                        if (act[k]) {
-                            if (STATS && c0 == 0) st_lv++;
-                            const float f = pu[k] - pv[k];
-                            const bool left = f < n[k].thresh;
-                            const bool cont = (n[k].flags & (left ? 1u : 2u)) != 0u;
-                            const uint32_t side = left ? 0u : 1u;
-                            if (cont) {
-                                g[k] = g[k] * 2u + side;
-                            } else {
-                                leaf[k] = (int)(((lvl + g[k]) << 1) | side);
-                                act[k] = false;
+                            for (int c = 0; c < CMAX; ++c) {
+                                if (c0 + c < a.C) pdf[c] = pdf[c] + pp[c];
                             }
                         }
                     }
                 }
 
-                // leaf PDFs, strictly in tree order (canonical sum order)
 #pragma unroll
-                for (int k = 0; k < kGroup; ++k) {
-                    if (leaf[k] >= 0) {
-                        any_leaf = true;
-                        if (STATS && c0 == 0) st_lf++;
-                        const float *pp = a.forest +
-                            ((size_t)(kb + k) * (size_t)a.nodes + (uint32_t)(leaf[k] >> 1)) * (size_t)a.E +
-                            7 + (leaf[k] & 1) * a.C + c0;
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c) {
-                            if (c0 + c < a.C) pdf[c] = pdf[c] + pp[c];
-                        }
+                for (int c = 0; c < CMAX; ++c) {
+                    if (c0 + c < a.C && pdf[c] > best) {
+                        best = pdf[c];
+                        best_c = c0 + c;
                     }
                 }
             }
 
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c) {
-                if (c0 + c < a.C && pdf[c] > best) {
-                    best = pdf[c];
-                    best_c = c0 + c;
-                }
-            }
+            if (STATS) st_px++;
+            if (a.keep_if_no_leaf && !any_leaf) continue;
+            a.labels[i] = (uint16_t)best_c;
         }
+    }
 
-        if (STATS) st_px++;
-        if (a.keep_if_no_leaf && !any_leaf) continue;
-        a.labels[i] = (uint16_t)best_c;
+    // ---- scheduler epilogue: the last workgroup to finish puts the slot back to zero (every
+    // workgroup has made its final, failing pull before it gets here) ----
+    if (a.sched && tid == 0) {
+        const unsigned int done = atomicAdd(a.sched + 1, 1u);
+        if (done == gridDim.x - 1u) {
+            atomicExch(a.sched + 0, 0u);
+            atomicExch(a.sched + 1, 0u);
+        }
     }
 
     if (STATS) {
@@ -269,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             st_lv += __shfl_down(st_lv, o);
             st_lf += __shfl_down(st_lf, o);
         }
-        if ((tid & 63) == 0) {
+        if (lane == 0) {
             atomicAdd(a.stats + 0, st_px);
             atomicAdd(a.stats + 1, st_lv);
             atomicAdd(a.stats + 2, st_lf);
@@ -286,7 +418,7 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec *pack
     NodeRec n;
     n.sux = s * p[0]; n.suy = s * p[1]; n.svx = s * p[2]; n.svy = s * p[3];
     n.thresh = p[4];
-    n.flags = child_flags(p[5], p[6]);
+    n.flags = node_flags(n.sux, n.suy, n.svx, n.svy, p[5], p[6]);
     n.pad0 = n.pad1 = 0;
     packed[i] = n;
 }
@@ -383,34 +515,92 @@ int device_info(DeviceInfo *out)
     return 0;
 }
 
+// ---- scheduler slots: one per (device, stream) that has launched; beyond kSchedSlots distinct
+// streams the kernel falls back to static round-robin chunks (sched == nullptr) ----
+std::mutex g_sched_mu;
+std::map<std::pair<int, void *>, int> g_sched_slot;
+std::map<int, unsigned int *> g_sched_base;     // device -> address of g_sched on that device
+int g_sched_mode = -1;                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic
+
+unsigned int *sched_slot(void *stream)
+{
+    int mode = g_sched_mode;
+    if (mode < 0) {
+        const char *v = getenv("RDF_SCHED");
+        mode = (v && strcmp(v, "static") == 0) ? 0 : 1;
+    }
+    if (mode == 0) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    auto bit = g_sched_base.find(dev);
+    if (bit == g_sched_base.end()) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched)) != hipSuccess || !p) return nullptr;
+        bit = g_sched_base.emplace(dev, reinterpret_cast<unsigned int *>(p)).first;
+    }
+    const auto key = std::make_pair(dev, stream);
+    auto it = g_sched_slot.find(key);
+    if (it == g_sched_slot.end()) {
+        int used = 0;
+        for (const auto &kv : g_sched_slot) used += kv.first.first == dev;
+        if (used >= kSchedSlots) return nullptr;
+        it = g_sched_slot.emplace(key, used).first;
+    }
+    return bit->second + 2 * it->second;
+}
+
+struct LaunchGeom {
+    int blocks_per_cu;
+};
+std::map<std::pair<const void *, int>, int> g_occ_cache;
+
 template <int BLOCK, bool PACKED, int CMAX, bool STATS>
-int launch_variant(const EvalArgs &a, int lds_bytes, int grid, hipStream_t st)
+int launch_variant(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
     auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS>;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
+    const void *kp = reinterpret_cast<const void *>(kern);
+    int per_cu = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        auto it = g_occ_cache.find({kp, lds_bytes});
+        if (it != g_occ_cache.end()) per_cu = it->second;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds_bytes, st, a);
+    if (per_cu == 0) {
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, BLOCK, (size_t)lds_bytes) != hipSuccess || n < 1)
+            n = 1;
+        per_cu = n;
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        g_occ_cache[{kp, lds_bytes}] = per_cu;
+    }
+    // persistent workgroups: as many as are resident at once, never more than there are tiles
+    long long grid = (long long)cus * per_cu;
+    if (grid > (long long)a.n_tiles) grid = a.n_tiles;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, a);
     return (int)hipGetLastError();
 }
 
 template <int BLOCK, bool PACKED, bool STATS>
-int launch_cmax(const EvalArgs &a, int lds_bytes, int grid, hipStream_t st)
+int launch_cmax(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    if (a.C <= 4) return launch_variant<BLOCK, PACKED, 4, STATS>(a, lds_bytes, grid, st);
-    if (a.C <= 8) return launch_variant<BLOCK, PACKED, 8, STATS>(a, lds_bytes, grid, st);
-    return launch_variant<BLOCK, PACKED, 16, STATS>(a, lds_bytes, grid, st);
+    if (a.C <= 4) return launch_variant<BLOCK, PACKED, 4, STATS>(a, lds_bytes, cus, st);
+    if (a.C <= 8) return launch_variant<BLOCK, PACKED, 8, STATS>(a, lds_bytes, cus, st);
+    return launch_variant<BLOCK, PACKED, 16, STATS>(a, lds_bytes, cus, st);
 }
 
 template <bool PACKED, bool STATS>
-int launch_block(int block, const EvalArgs &a, int lds_bytes, int grid, hipStream_t st)
+int launch_block(int block, const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
     switch (block) {
-    case 256: return launch_cmax<256, PACKED, STATS>(a, lds_bytes, grid, st);
-    case 512: return launch_cmax<512, PACKED, STATS>(a, lds_bytes, grid, st);
-    default: return launch_cmax<1024, PACKED, STATS>(a, lds_bytes, grid, st);
+    case 256: return launch_cmax<256, PACKED, STATS>(a, lds_bytes, cus, st);
+    case 512: return launch_cmax<512, PACKED, STATS>(a, lds_bytes, cus, st);
+    default: return launch_cmax<1024, PACKED, STATS>(a, lds_bytes, cus, st);
     }
 }
 
@@ -446,11 +636,9 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const No
     memset(&a, 0, sizeof(a));
     a.depth = depth; a.forest = forest; a.packed = packed; a.filter = filter; a.labels = labels_out;
     a.stats = stats;
-    a.W = dim_x; a.H = dim_y; a.Wl = dim_x / r; a.r = r;
-    const int Hl = dim_y / r;
-    a.per_img_l = (uint32_t)a.Wl * (uint32_t)Hl;
+    a.W = dim_x; a.H = dim_y; a.Wl = dim_x / r; a.Hl = dim_y / r; a.r = r;
+    a.per_img_l = (uint32_t)a.Wl * (uint32_t)a.Hl;
     a.per_img_d = (uint32_t)dim_x * (uint32_t)dim_y;
-    a.total = a.per_img_l * (uint32_t)n_img;
     a.T = n_trees; a.D = max_depth; a.C = n_classes; a.E = 7 + 2 * n_classes;
     a.nodes = (int)((1ll << max_depth) - 1);
     a.filter_class = filter_class;
@@ -460,30 +648,31 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const No
     // top levels that fit the LDS budget: T * (2^K - 1) * 32 B <= budget
     int K = 0;
     const long long budget = lds_budget();
-    while (K < max_depth && (long long)n_trees * ((1ll << (K + 1)) - 1) * 32 <= budget) ++K;
+    while (K < max_depth && (long long)n_trees * ((1ll << (K + 1)) - 1) * 32 + 16 <= budget) ++K;
     a.lds_levels = K;
-    const int lds_bytes = (int)((long long)n_trees * ((1ll << K) - 1) * 32);
+    const int lds_bytes = (int)((long long)n_trees * ((1ll << K) - 1) * 32) + 16; // + queue mailbox
 
     int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
+    a.tiles_x = ((uint32_t)a.Wl + 63u) / 64u;
     if (block != 256 && block != 512 && block != 1024) {
         // small launches: smaller workgroups spread over more CUs
-        const long long t1024 = ((long long)a.total + 1023) / 1024;
-        block = t1024 >= 2ll * di.cus ? 1024 : (t1024 * 2 >= 2ll * di.cus ? 512 : 256);
+        const long long groups = (long long)n_img * a.tiles_x * ((a.Hl + kChunkGroups - 1) / kChunkGroups);
+        block = groups >= 32ll * di.cus ? 1024 : (groups >= 16ll * di.cus ? 512 : 256);
     }
-    a.n_tiles = (uint32_t)(((long long)a.total + block - 1) / block);
-    const int per_cu = block == 1024 ? 2 : (block == 512 ? 4 : 8);
-    long long grid = (long long)di.cus * per_cu; // multiple of 8 on MI355X (256 CUs)
-    grid -= grid % 8;
-    if (grid < 8) grid = 8;
-    if ((long long)a.n_tiles < grid) grid = a.n_tiles;
+    const uint32_t tile_rows = (uint32_t)(block / 64) * kChunkGroups;
+    a.tiles_y = ((uint32_t)a.Hl + tile_rows - 1u) / tile_rows;
+    const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
+    if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    a.n_tiles = (uint32_t)n_tiles;
+    a.sched = sched_slot(stream);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (stats) {
-        return packed ? launch_block<true, true>(block, a, lds_bytes, (int)grid, st)
-                      : launch_block<false, true>(block, a, lds_bytes, (int)grid, st);
+        return packed ? launch_block<true, true>(block, a, lds_bytes, di.cus, st)
+                      : launch_block<false, true>(block, a, lds_bytes, di.cus, st);
     }
-    return packed ? launch_block<true, false>(block, a, lds_bytes, (int)grid, st)
-                  : launch_block<false, false>(block, a, lds_bytes, (int)grid, st);
+    return packed ? launch_block<true, false>(block, a, lds_bytes, di.cus, st)
+                  : launch_block<false, false>(block, a, lds_bytes, di.cus, st);
 }
 
 } // namespace
@@ -541,6 +730,7 @@ int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_
                            int labels_reduce, void *stream)
 {
     if (!packed && n_trees > 0 && max_depth > 0) return RDF_ERR_NULL_PTR;
+    if (max_depth > 27) return RDF_ERR_BAD_ARG; // packed records are addressed with 32-bit byte offsets
     if (!packed) // degenerate forest: nothing to walk, the unpacked path handles it
         return eval_common(depth, n_img, dim_x, dim_y, nullptr, forest, n_trees, max_depth, n_classes, filter,
                            filter_class, labels_out, labels_reduce, 1.0f, 0, nullptr, stream);
@@ -595,6 +785,7 @@ int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, 
 
 void rdf_set_lds_budget_bytes(int bytes) { g_lds_budget = bytes; }
 void rdf_set_block_threads(int threads) { g_block_threads = threads; }
+void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
 
 int rdf_event_create(void **event)
 {

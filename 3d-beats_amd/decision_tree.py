@@ -217,7 +217,9 @@ class DecisionTreeEvaluator:
         lib, st = self._lib, self._rt.stream()
         filter_class = int(filter_images_class) if filter_images is not None else -1
         lpix = (dim_y // labels_reduce) * (dim_x // labels_reduce)
-        packed = forest.packed(scale_factor) if (self.use_packed and hasattr(forest, "packed")) else None
+        packed = None
+        if self.use_packed and hasattr(forest, "packed") and forest.max_depth <= 27:
+            packed = forest.packed(scale_factor)
         for i0, n in _image_chunks(num_images, dim_y * dim_x):
             d = _at(depth_images_in, i0, dim_y * dim_x * 2)
             o = _at(labels_out, i0, lpix * 2)

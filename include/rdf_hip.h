@@ -74,6 +74,7 @@ int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, 
  * child flags}.  The reference has no counterpart: its "load" is the plain upload at
  * src/decision_tree.py:148-158.  The packed table depends on scale_factor and must be rebuilt
  * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes.
+ * Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
@@ -108,6 +109,7 @@ int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, 
 /* Tuning knobs (process-wide; 0 restores the default).  Not part of the reference surface. */
 void rdf_set_lds_budget_bytes(int bytes);
 void rdf_set_block_threads(int threads); /* 256, 512 or 1024 */
+void rdf_set_scheduler(int mode);        /* 1 dynamic chunk queue (default), 0 static round-robin, -1 env RDF_SCHED */
 
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
 int rdf_event_create(void **event);

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of launch geometries (block threads x LDS budget) of the forest kernel on
+the bench workload.  usage: python3 tools/sweep.py [--frames 128] [--rounds 5] block:lds ..."""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--trees", type=int, default=4)
+    ap.add_argument("--topology", default="full")
+    ap.add_argument("--unpacked", action="store_true")
+    ap.add_argument("--kinds", default="mixed", choices=["mixed", "interleaved", "dense", "live"])
+    ap.add_argument("combos", nargs="*", default=["1024:81920", "512:81920", "512:32768", "256:32768", "256:16384"])
+    a = ap.parse_args()
+    import torch
+    rdf = importlib.import_module("3d-beats_amd")
+    rt = rdf.get_runtime()
+    lib = rt.lib
+    forest = rdf.DecisionForest.from_numpy(rdf.synth.forest(a.trees, a.depth, 4, a.topology))
+    kinds = {"mixed": None, "interleaved": ["dense", "live"] * (a.frames // 2) + ["dense"] * (a.frames % 2),
+             "dense": ["dense"] * a.frames, "live": ["live"] * a.frames}[a.kinds]
+    host = rdf.synth.mixed_batch(a.frames) if kinds is None else rdf.synth.frames(kinds)
+    depth = rdf.to_device(host)
+    labels = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
+    ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
+    combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]
+    res = {c: [] for c in combos}
+    ref = None
+    for r in range(a.rounds + 1):
+        for c in combos:
+            lib.rdf_set_block_threads(c[0])
+            lib.rdf_set_lds_budget_bytes(c[1] if c[1] else 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev.get_labels_forest(forest, depth, labels)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if r:
+                res[c].append(dt * 1e3)
+            else:
+                got = labels.get()
+                ref = got if ref is None else ref
+                assert np.array_equal(got, ref), c
+    npx = a.frames * 480 * 848
+    for c in combos:
+        v = np.array(res[c])
+        print(f"block {c[0]:5d} lds {c[1]:7d}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
+              f"{npx / np.median(v) / 1e3:8.1f} Mpix/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
