@@ -30,6 +30,9 @@ SIGNATURES = {
     "rdf_set_lds_budget_bytes": (None, [_c_int]),
     "rdf_set_block_threads": (None, [_c_int]),
     "rdf_set_scheduler": (None, [_c_int]),
+    "rdf_set_halo": (None, [_c_int]),
+    "rdf_set_rows_per_wave": (None, [_c_int]),
+    "rdf_set_force_exact": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),
     "rdf_event_record": (_c_int, [_c_void_p, _c_void_p]),
     "rdf_event_synchronize": (_c_int, [_c_void_p]),

@@ -9,15 +9,22 @@
 //     4 rows per wave, rows of the waves interleaved) so that the probe neighbourhoods of its waves
 //     overlap in the CU's L1; the centre-depth read and the label store are one 128-byte line;
 //   * per-tree leaf PDFs are added in registers in tree order (canonical order, no atomics);
-//   * the top levels of every tree live in LDS as 32-byte records {s*u, s*v, thresh, flags};
-//     deeper levels are fetched from a packed 32-byte-record table (rdf_forest_pack) or, for
-//     the unpacked entry point, straight from the reference's 7+2C-float records;
+//   * node records are 16 bytes {int24 floor(s*u), int24 floor(s*v), integer threshold, flags}:
+//     the top levels of every tree live in LDS, deeper levels are ONE 128-bit load each from the
+//     packed table (rdf_forest_pack) or, for the unpacked entry point, the reference's own
+//     7+2C-float records.  The kernel is bound by the L1 tag rate (one cache line per clock per
+//     CU, profiles/), so what counts is lines touched per wave instruction, not bytes;
+//   * the workgroup's depth tile plus a halo is staged in LDS (out-of-image cells = 65535), so
+//     most probes are LDS reads with no bounds check; far probes go to global memory;
 //   * tiles are handed to persistent workgroups by a device-side queue (one atomic per tile), so
 //     empty (background) tiles cost almost nothing and frames of unequal cost balance out.
 //
-// Bit-exactness: (s*u)/d is one fp32 multiply and one IEEE-correct fp32 divide (hipcc's default
-// v_div_scale/v_div_fmas/v_div_fixup sequence; never build this file with -ffast-math), floor +
-// saturating convert is v_floor_f32 + v_cvt_i32_f32, coordinate adds wrap, bounds are checked per axis.
+// Bit-exactness: the reference computes floor((s*u)/d) with one fp32 multiply, one IEEE-correct
+// fp32 divide and __float2int_rd.  The fast path here (integer numerator, shared refined
+// reciprocal, one fma correction) is proven equal to that for every depth value and every
+// numerator it is used for by exhaustive GPU enumeration (tools/verify_*.hip); all other
+// numerators take hipcc's IEEE divide (never build this file with -ffast-math) followed by
+// v_floor_f32 + v_cvt_i32_f32.  Coordinate adds wrap, bounds are checked per axis.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,44 +40,67 @@
 namespace {
 
 constexpr int kGroup = 4;          // trees walked interleaved by one lane
-constexpr int kChunkGroups = 4;    // 64-pixel groups a wave takes per scheduler pull
-constexpr int kDefaultLdsBudget = 80 * 1024;
+constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
+constexpr int kDefaultLdsBudget = 40000;   // node table + depth tile per workgroup
+constexpr int kDefaultHalo = 16;   // depth pixels staged around a tile's centres
 constexpr uint32_t kNoPixel = 65535u;
-constexpr uint32_t kFlagLeft = 1u, kFlagRight = 2u, kFlagSlowDiv = 4u;
+constexpr uint32_t kFlagLeft = 1u, kFlagRight = 2u, kFlagExact = 4u;
 constexpr int kSchedSlots = 256;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Dynamic chunk scheduler state, one slot per (device, stream) in use: {next chunk, waves finished}.
-// Zero at rest: the last wave of a launch resets its slot, so launches need no memset and replay
-// correctly from a captured hipGraph.
+// Dynamic tile queue state, one slot per (device, stream) in use: {next tile, workgroups finished}.
+// Zero at rest: the last workgroup of a launch resets its slot, so launches need no memset and
+// replay correctly from a captured hipGraph.
 __device__ unsigned int g_sched[kSchedSlots][2];
 
-struct alignas(16) NodeRec {       // 32 bytes
-    float sux, suy, svx, svy;      // scale_factor * (u.x, u.y, v.x, v.y)
-    float thresh;
-    uint32_t flags;                // kFlagLeft / kFlagRight: that child continues; kFlagSlowDiv
-    uint32_t pad0, pad1;
+// ---- node records --------------------------------------------------------------------------
+// Hot record, 16 bytes, one 128-bit load per node:
+//   w0 = int24 floor(s*u.x) | T[7:0]   << 24        T = integer threshold (see thresh_to_int)
+//   w1 = int24 floor(s*u.y) | T[15:8]  << 24
+//   w2 = int24 floor(s*v.x) | T[17:16] << 24
+//   w3 = int24 floor(s*v.y) | flags    << 24        flags: kFlagLeft/Right = that child continues,
+//                                                          kFlagExact = use the exact record
+// Why integers are enough: for every depth d in [1,65534] and every fp32 a that is +-0 or has a
+// biased exponent in [40,149] (|a| < 2^23), floor(IEEE a/d) == floor(fastdiv(float(floor(a)), d))
+// -- checked exhaustively on gfx950 by tools/verify_intoffset.hip and tools/verify_fastdiv.hip
+// (1.2e14 and 2.1e14 pairs, 0 mismatches; logs under profiles/).  Any other numerator (huge,
+// denormal, inf, NaN) flags the node kFlagExact and the kernel takes the IEEE divide on the fp32
+// values of the exact record.
+struct alignas(16) NodeRec16 {
+    uint32_t w[4];
 };
-static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+// Exact record, 32 bytes: the fp32 numerators s*u, s*v (read only for kFlagExact nodes).
+struct alignas(16) NodeRec32 {
+    float sux, suy, svx, svy;
+    float thresh;
+    uint32_t flags, pad0, pad1;
+};
+static_assert(sizeof(NodeRec16) == 16 && sizeof(NodeRec32) == 32, "record sizes");
 
 struct EvalArgs {
     const uint16_t *depth;
     const float *forest;
-    const NodeRec *packed;
+    const NodeRec16 *packed16;   // nullptr on the unpacked path
+    const NodeRec32 *packed32;
     const uint16_t *filter;
     uint16_t *labels;
     unsigned long long *stats;
-    unsigned int *sched;   // scheduler slot, or nullptr for static round-robin chunks
+    unsigned int *sched;   // queue slot, or nullptr for static round-robin tiles
     uint32_t n_tiles;      // n_img * tiles_x * tiles_y
     uint32_t tiles_x;      // ceil(Wl / 64)
-    uint32_t tiles_y;      // ceil(Hl / (waves per block * kChunkGroups))
+    uint32_t tiles_y;      // ceil(Hl / (waves per block * rows_per_wave))
+    int rows_per_wave;     // 1..kMaxRowsPerWave
     uint32_t per_img_l;    // Wl*Hl
     uint32_t per_img_d;    // W*H
     int W, H, Wl, Hl, r;
     int T, D, C, E;
     int nodes;             // 2^D - 1
     int lds_levels;        // top levels held in LDS
+    int halo;              // depth pixels around the tile's centres held in LDS
+    int tw, th, twp;       // staged depth tile: width, height, row pitch (0: no staged tile)
+    uint32_t lds_tile_off; // byte offsets inside the dynamic LDS allocation
+    uint32_t lds_mail_off;
     int filter_class;
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
     float s;
@@ -103,105 +133,136 @@ __device__ __forceinline__ uint32_t child_flags(float l, float r)
     return ((l >= -1.0f && l < 0.0f) ? kFlagLeft : 0u) | ((r >= -1.0f && r < 0.0f) ? kFlagRight : 0u);
 }
 
-// The shared-reciprocal divide (see eval loop) is proven equal to the IEEE divide, in floor-to-int,
-// for every depth 1..65534 and every numerator that is +-0 or has a biased exponent in [40, 230]
-// (tools/verify_fastdiv.hip, exhaustive on gfx950).  Anything else takes the IEEE path.
-__device__ __forceinline__ bool needs_ieee_divide(float a)
+// Numerators the integer record represents exactly (see NodeRec16): +-0, or biased exponent 40..149.
+__device__ __forceinline__ bool int_offset_ok(float a)
 {
     const uint32_t b = __float_as_uint(a);
-    return (b << 1) != 0u && (((b >> 23) & 0xFFu) - 40u) > 190u;
+    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 109u;
 }
 
-__device__ __forceinline__ uint32_t node_flags(float sux, float suy, float svx, float svy, float l, float r)
+// f = depth[u] - depth[v] is an integer in [-65535, 65535], so `f < thresh` (tree_eval.cu:107)
+// equals `f < T` with T = ceil(thresh) clamped to [-65535, 65536]; NaN never compares true.
+__device__ __forceinline__ int thresh_to_int(float t)
 {
-    const bool slow = needs_ieee_divide(sux) | needs_ieee_divide(suy) | needs_ieee_divide(svx) | needs_ieee_divide(svy);
-    return child_flags(l, r) | (slow ? kFlagSlowDiv : 0u);
+    if (t != t) return -65535;
+    const float c = fminf(fmaxf(__builtin_ceilf(t), -65535.0f), 65536.0f);
+    return (int)c;
 }
 
-// Depth probe with per-axis bounds check, out of bounds -> 65535 (cu_utils.hpp:79-86).
-// `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets (batch < 2^31 pixels).
-__device__ __forceinline__ float probe(const char *depth_b, uint32_t img_boff, int x, int y, int W, int H)
+__device__ __forceinline__ NodeRec16 encode_node(float sux, float suy, float svx, float svy, float thresh,
+                                                 float l_next, float r_next)
 {
-    const bool inb = (uint32_t)x < (uint32_t)W && (uint32_t)y < (uint32_t)H;
-    const uint32_t off = inb ? img_boff + (((uint32_t)y * (uint32_t)W + (uint32_t)x) << 1) : img_boff;
-    const uint32_t v = *reinterpret_cast<const uint16_t *>(depth_b + off);
-    return inb ? (float)v : 65535.0f;
+    uint32_t flags = child_flags(l_next, r_next);
+    const bool ok = int_offset_ok(sux) && int_offset_ok(suy) && int_offset_ok(svx) && int_offset_ok(svy);
+    int nx = 0, ny = 0, mx = 0, my = 0;
+    if (ok) {
+        nx = (int)__builtin_floorf(sux); ny = (int)__builtin_floorf(suy);
+        mx = (int)__builtin_floorf(svx); my = (int)__builtin_floorf(svy);
+    } else {
+        flags |= kFlagExact;
+    }
+    const uint32_t t = (uint32_t)thresh_to_int(thresh) & 0x3FFFFu;
+    NodeRec16 r;
+    r.w[0] = ((uint32_t)nx & 0xFFFFFFu) | ((t & 0xFFu) << 24);
+    r.w[1] = ((uint32_t)ny & 0xFFFFFFu) | (((t >> 8) & 0xFFu) << 24);
+    r.w[2] = ((uint32_t)mx & 0xFFFFFFu) | (((t >> 16) & 0x3u) << 24);
+    r.w[3] = ((uint32_t)my & 0xFFFFFFu) | (flags << 24);
+    return r;
+}
+
+__device__ __forceinline__ uint4 select4(bool c, const uint4 a, const uint4 b)
+{
+    return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 
 struct Node {
-    float sux, suy, svx, svy, thresh;
+    float ax, ay, bx, by;   // numerators of the u and v offsets (integers on the fast path)
+    int t;                  // integer threshold
     uint32_t flags;
 };
 
-// Node record of tree `tree` (wave-uniform) at level-order index idx, from global memory.
-template <bool PACKED>
-__device__ __forceinline__ Node load_global_node(const EvalArgs &a, int tree, uint32_t idx)
+__device__ __forceinline__ Node decode_node(const uint4 w)
 {
     Node n;
-    if (PACKED) {
-        const char *base = reinterpret_cast<const char *>(a.packed + (size_t)tree * (size_t)a.nodes);
-        const uint32_t off = idx * 32u;
-        const float4 v = *reinterpret_cast<const float4 *>(base + off);
-#ifdef RDF_ABLATE_NODE2
-        const float2 w = {v.x * 1e-3f, __uint_as_float(3u)};   // timing experiment: one load per node
-#else
-        const float2 w = *reinterpret_cast<const float2 *>(base + off + 16u);
-#endif
-        n.sux = v.x; n.suy = v.y; n.svx = v.z; n.svy = v.w;
-        n.thresh = w.x; n.flags = __float_as_uint(w.y);
-    } else {
-        const float *p = a.forest + ((size_t)tree * (size_t)a.nodes + idx) * (size_t)a.E;
-        n.sux = a.s * p[0]; n.suy = a.s * p[1]; n.svx = a.s * p[2]; n.svy = a.s * p[3];
-        n.thresh = p[4];
-        n.flags = child_flags(p[5], p[6]) | kFlagSlowDiv;   // the unpacked path always divides IEEE
-    }
+    n.ax = (float)((int)(w.x << 8) >> 8);
+    n.ay = (float)((int)(w.y << 8) >> 8);
+    n.bx = (float)((int)(w.z << 8) >> 8);
+    n.by = (float)((int)(w.w << 8) >> 8);
+    const uint32_t t = (w.x >> 24) | ((w.y >> 24) << 8) | ((w.z >> 24) << 16);
+    n.t = (int)(t << 14) >> 14;
+    n.flags = w.w >> 24;
     return n;
 }
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS>
+// Depth value at (x, y) of the current image: from the staged LDS tile when the coordinate falls
+// inside it (cells outside the image already hold 65535), else from global memory with the per-axis
+// bounds check of cu_utils.hpp:79-86.  `depth_b` is the wave-uniform batch base; offsets are 32-bit
+// byte offsets (a call addresses < 2^31 pixels).
+__device__ __forceinline__ int probe(const uint16_t *tile, int tx0, int ty0, int tw, int th, int twp,
+                                     const char *depth_b, uint32_t img_boff, int x, int y, int W, int H)
+{
+    const int cx = x - tx0, cy = y - ty0;
+    uint32_t v;
+    if ((uint32_t)cx < (uint32_t)tw && (uint32_t)cy < (uint32_t)th) {
+        v = tile[cy * twp + cx];
+    } else {
+        const bool inb = (uint32_t)x < (uint32_t)W && (uint32_t)y < (uint32_t)H;
+        const uint32_t off = inb ? img_boff + (((uint32_t)y * (uint32_t)W + (uint32_t)x) << 1) : img_boff;
+        v = *reinterpret_cast<const uint16_t *>(depth_b + off);
+        v = inb ? v : kNoPixel;
+    }
+    return (int)v;
+}
+
+// FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
+// a.rows_per_wave rows (latency shape for small launches such as one live frame).
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
 __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    NodeRec *lds = reinterpret_cast<NodeRec *>(lds_raw);
+    uint4 *lds_nodes = reinterpret_cast<uint4 *>(lds_raw);
+    uint16_t *lds_tile = reinterpret_cast<uint16_t *>(lds_raw + a.lds_tile_off);
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(lds_raw + a.lds_mail_off);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int K = a.lds_levels;
     const uint32_t nodes_lds = (1u << K) - 1u;
+    constexpr uint32_t kWaves = BLOCK / 64;
+    const int rows_per_wave = FULLROWS ? kMaxRowsPerWave : a.rows_per_wave;
+    const uint32_t tile_rows = kWaves * (uint32_t)rows_per_wave;
+    const uint32_t wave = (uint32_t)tid >> 6;
 
-    // ---- stage the top K levels of every tree (level order => the first 2^K-1 records) ----
-    for (uint32_t i = tid; i < (uint32_t)a.T * nodes_lds; i += BLOCK) {
-        const uint32_t k = i / nodes_lds, nn = i - k * nodes_lds;
-        NodeRec rec;
+    // ---- stage the top K levels of every tree.  Tables use 1-based heap numbering (slot 0 unused):
+    // node h has children 2h and 2h+1, which therefore share one aligned 32-byte pair ----
+    const uint32_t lds_pitch = 1u << K;   // records per tree in LDS
+    for (uint32_t i = tid; i < (uint32_t)a.T * lds_pitch; i += BLOCK) {
+        const uint32_t k = i >> K, h = i & (lds_pitch - 1u);
+        if (h == 0u) continue;
         if (PACKED) {
-            rec = a.packed[(size_t)k * (size_t)a.nodes + nn];
+            lds_nodes[i] = reinterpret_cast<const uint4 *>(a.packed16)[((size_t)k << a.D) + h];
         } else {
-            const Node n = load_global_node<false>(a, (int)k, nn);
-            rec.sux = n.sux; rec.suy = n.suy; rec.svx = n.svx; rec.svy = n.svy;
-            rec.thresh = n.thresh; rec.flags = n.flags; rec.pad0 = rec.pad1 = 0;
+            const float *p = a.forest + ((size_t)k * (size_t)a.nodes + (h - 1u)) * (size_t)a.E;
+            const NodeRec16 r = encode_node(a.s * p[0], a.s * p[1], a.s * p[2], a.s * p[3], p[4], p[5], p[6]);
+            lds_nodes[i] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
         }
-        lds[i] = rec;
     }
-    __syncthreads();
+    // (made visible by the first tile's barriers)
 
     unsigned long long st_px = 0, st_lv = 0, st_lf = 0;
     const char *depth_b = reinterpret_cast<const char *>(a.depth);
-    constexpr uint32_t kWaves = BLOCK / 64;
-    constexpr uint32_t kTileRows = kWaves * kChunkGroups;
-    const uint32_t wave = (uint32_t)tid >> 6;
-    // queue mailbox lives behind the node table in the one dynamic LDS allocation (a second,
-    // static __shared__ object could push the dynamic base off 16-byte alignment)
-    uint32_t *s_tile = reinterpret_cast<uint32_t *>(lds + (size_t)a.T * nodes_lds);
+    const int tw = a.tw, th = a.th, twp = a.twp;
     uint32_t static_tile = blockIdx.x;
 
     for (uint32_t it = 0;; ++it) {
-        // ---- take the next tile: 64 label columns x kTileRows label rows of one image ----
+        // ---- take the next tile: 64 label columns x tile_rows label rows of one image ----
         uint32_t tile;
         if (a.sched) {
             if (tid == 0) s_tile[it & 1u] = atomicAdd(a.sched, 1u);
-            __syncthreads();   // one barrier per tile: the slot written next is the other one
+            __syncthreads();   // also: every wave is done with the previous tile's LDS image
             tile = s_tile[it & 1u];
         } else {
+            __syncthreads();
             tile = static_tile;
             static_tile += gridDim.x;
         }
@@ -214,10 +275,30 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         const int lx = (int)(tx * 64u) + lane;
         const uint32_t img_boff = (img * a.per_img_d) << 1;
         const uint32_t img_loff = img * a.per_img_l;
+        // depth coordinates of the staged tile's first cell
+        const int tx0 = (int)(tx * 64u) * a.r - a.halo;
+        const int ty0 = (int)(ty * tile_rows) * a.r - a.halo;
 
-        for (int sub = 0; sub < kChunkGroups; ++sub) {
+        // ---- stage depth [ty0, ty0+th) x [tx0, tx0+tw) into LDS; outside the image = 65535 ----
+        if (tw > 0) {
+            for (int row = (int)wave; row < th; row += (int)kWaves) {
+                const int gy = ty0 + row;
+                const bool row_in = (uint32_t)gy < (uint32_t)a.H;
+                for (int col = lane; col < tw; col += 64) {
+                    const int gx = tx0 + col;
+                    uint32_t v = kNoPixel;
+                    if (row_in && (uint32_t)gx < (uint32_t)a.W)
+                        v = *reinterpret_cast<const uint16_t *>(
+                            depth_b + (img_boff + (((uint32_t)gy * (uint32_t)a.W + (uint32_t)gx) << 1)));
+                    lds_tile[row * twp + col] = (uint16_t)v;
+                }
+            }
+            __syncthreads();
+        }
+
+        for (int sub = 0; sub < rows_per_wave; ++sub) {
             // rows of the workgroup's waves are interleaved: at any time they cover adjacent rows
-            const int ly = (int)(ty * kTileRows + (uint32_t)sub * kWaves + wave);
+            const int ly = (int)(ty * tile_rows + (uint32_t)sub * kWaves + wave);
             if (ly >= a.Hl || lx >= a.Wl) continue;
             const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
             const int x = lx * a.r, y = ly * a.r;
@@ -225,8 +306,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             if (a.filter_class != -1) {
                 if ((int)a.filter[i] != a.filter_class) continue;
             }
-            const uint32_t d = *reinterpret_cast<const uint16_t *>(
-                depth_b + (img_boff + (((uint32_t)y * (uint32_t)a.W + (uint32_t)x) << 1)));
+            const uint32_t d = (uint32_t)probe(lds_tile, tx0, ty0, tw, th, twp, depth_b, img_boff, x, y, a.W, a.H);
             if (d == 0u || d == kNoPixel) continue;
             const float df = (float)d;
             // refined reciprocal shared by every divide of this pixel (fast path only)
@@ -245,12 +325,12 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                 for (int c = 0; c < CMAX; ++c) pdf[c] = 0.0f;
 
                 for (int kb = 0; kb < a.T; kb += kGroup) {
-                    uint32_t g[kGroup];
+                    uint32_t h[kGroup];     // 1-based heap index of the current node
                     int leaf[kGroup];
                     bool act[kGroup];
 #pragma unroll
                     for (int k = 0; k < kGroup; ++k) {
-                        g[k] = 0u;
+                        h[k] = 1u;
                         leaf[k] = -1;
                         act[k] = (kb + k) < a.T;
                     }
@@ -261,52 +341,72 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                         for (int k = 0; k < kGroup; ++k) any |= act[k];
                         if (!__any(any)) break;
 
-                        const uint32_t lvl = (1u << j) - 1u;
+                        const bool in_lds = j < K;
                         Node n[kGroup];
-                        if (j < K) {
+                        if (in_lds) {
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
                                 const uint32_t tk = (uint32_t)min(kb + k, a.T - 1);   // wave-uniform
-                                const uint32_t idx = act[k] ? lvl + g[k] : 0u;
-                                const NodeRec *p = lds + tk * nodes_lds + idx;
-                                const float4 v = *reinterpret_cast<const float4 *>(p);
-                                const float2 w = *reinterpret_cast<const float2 *>(&p->thresh);
-                                n[k].sux = v.x; n[k].suy = v.y; n[k].svx = v.z; n[k].svy = v.w;
-                                n[k].thresh = w.x; n[k].flags = __float_as_uint(w.y);
+                                n[k] = decode_node(lds_nodes[tk * lds_pitch + h[k]]);
+                            }
+                        } else if (PACKED) {
+#pragma unroll
+                            for (int k = 0; k < kGroup; ++k) {
+                                const int tk = min(kb + k, a.T - 1);
+                                const char *base = reinterpret_cast<const char *>(a.packed16 + ((size_t)tk << a.D));
+                                n[k] = decode_node(*reinterpret_cast<const uint4 *>(base + h[k] * 16u));
                             }
                         } else {
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
                                 const int tk = min(kb + k, a.T - 1);
-                                const uint32_t idx = act[k] ? lvl + g[k] : 0u;
-                                n[k] = load_global_node<PACKED>(a, tk, idx);
+                                const float *p = a.forest + ((size_t)tk * (size_t)a.nodes + (h[k] - 1u)) * (size_t)a.E;
+                                n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1]; n[k].bx = a.s * p[2]; n[k].by = a.s * p[3];
+                                n[k].t = thresh_to_int(p[4]);
+                                n[k].flags = child_flags(p[5], p[6]) | kFlagExact;   // fp32 numerators: IEEE divide
                             }
                         }
 
                         // ---- probe coordinates: x + floor((s*u.x)/d) ... (decision_tree_common.hpp:15-22) ----
                         int ux[kGroup], uy[kGroup], vx[kGroup], vy[kGroup];
-                        bool slow = !PACKED;
-                        if (PACKED) {
-                            uint32_t fl = 0u;
+                        uint32_t fl = 0u;
 #pragma unroll
-                            for (int k = 0; k < kGroup; ++k) fl |= n[k].flags;
-                            slow = __any((fl & kFlagSlowDiv) != 0u);
-                        }
-                        if (slow) {
+                        for (int k = 0; k < kGroup; ++k) fl |= n[k].flags;
+                        if (__any((fl & kFlagExact) != 0u)) {
+                            // some lane holds a node whose numerators are not integer-representable: fetch the
+                            // fp32 numerators for those lanes and divide IEEE (every lane: same results)
+                            if (PACKED || in_lds) {
+#pragma unroll
+                                for (int k = 0; k < kGroup; ++k) {
+                                    if (n[k].flags & kFlagExact) {
+                                        const int tk = min(kb + k, a.T - 1);
+                                        if (PACKED) {
+                                            const float4 e = *reinterpret_cast<const float4 *>(
+                                                a.packed32 + ((size_t)tk << a.D) + h[k]);
+                                            n[k].ax = e.x; n[k].ay = e.y; n[k].bx = e.z; n[k].by = e.w;
+                                        } else {
+                                            const float *p = a.forest +
+                                                ((size_t)tk * (size_t)a.nodes + (h[k] - 1u)) * (size_t)a.E;
+                                            n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1];
+                                            n[k].bx = a.s * p[2]; n[k].by = a.s * p[3];
+                                        }
+                                    }
+                                }
+                            }
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
-                                ux[k] = add_wrap(x, floor_i32(n[k].sux / df));
-                                uy[k] = add_wrap(y, floor_i32(n[k].suy / df));
-                                vx[k] = add_wrap(x, floor_i32(n[k].svx / df));
-                                vy[k] = add_wrap(y, floor_i32(n[k].svy / df));
+                                ux[k] = add_wrap(x, floor_i32(n[k].ax / df));
+                                uy[k] = add_wrap(y, floor_i32(n[k].ay / df));
+                                vx[k] = add_wrap(x, floor_i32(n[k].bx / df));
+                                vy[k] = add_wrap(y, floor_i32(n[k].by / df));
                             }
                         } else {
                             // q0 = a*rcp; rem = a - d*q0 (exact, fma); q = q0 + rem*rcp.  Packed f32 math,
                             // two quotients per instruction.
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
-                                const f2 nu = {n[k].sux, n[k].suy};
-                                const f2 nv = {n[k].svx, n[k].svy};
+                                const f2 nu = {n[k].ax, n[k].ay};
+                                const f2 nv = {n[k].bx, n[k].by};
                                 const f2 qu0 = nu * rcp2;
                                 const f2 qv0 = nv * rcp2;
                                 const f2 ru = __builtin_elementwise_fma(ndf2, qu0, nu);
@@ -320,32 +420,24 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             }
                         }
 
-                        float pu[kGroup], pv[kGroup];
+                        int pu[kGroup], pv[kGroup];
 #pragma unroll
                         for (int k = 0; k < kGroup; ++k) {
-                            pu[k] = probe(depth_b, img_boff, ux[k], uy[k], a.W, a.H);
-#ifdef RDF_ABLATE_VPROBE
-                            pv[k] = (float)(vx[k] ^ vy[k]);   // timing experiment: no second probe
-#else
-                            pv[k] = probe(depth_b, img_boff, vx[k], vy[k], a.W, a.H);
-#endif
-#ifdef RDF_ABLATE_UPROBE
-                            pu[k] = (float)(ux[k] ^ uy[k]);   // timing experiment: no probes at all
-#endif
+                            pu[k] = probe(lds_tile, tx0, ty0, tw, th, twp, depth_b, img_boff, ux[k], uy[k], a.W, a.H);
+                            pv[k] = probe(lds_tile, tx0, ty0, tw, th, twp, depth_b, img_boff, vx[k], vy[k], a.W, a.H);
                         }
 
 #pragma unroll
                         for (int k = 0; k < kGroup; ++k) {
                             if (act[k]) {
                                 if (STATS && c0 == 0) st_lv++;
-                                const float f = pu[k] - pv[k];
-                                const bool left = f < n[k].thresh;
+                                const bool left = (pu[k] - pv[k]) < n[k].t;
                                 const bool cont = (n[k].flags & (left ? kFlagLeft : kFlagRight)) != 0u;
                                 const uint32_t side = left ? 0u : 1u;
                                 if (cont) {
-                                    g[k] = g[k] * 2u + side;
+                                    h[k] = h[k] * 2u + side;
                                 } else {
-                                    leaf[k] = (int)(((lvl + g[k]) << 1) | side);
+                                    leaf[k] = (int)(((h[k] - 1u) << 1) | side);
                                     act[k] = false;
                                 }
                             }
@@ -384,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         }
     }
 
-    // ---- scheduler epilogue: the last workgroup to finish puts the slot back to zero (every
+    // ---- queue epilogue: the last workgroup to finish puts the slot back to zero (every
     // workgroup has made its final, failing pull before it gets here) ----
     if (a.sched && tid == 0) {
         const unsigned int done = atomicAdd(a.sched + 1, 1u);
@@ -409,18 +501,32 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
     }
 }
 
-// ---- load-time repack: one thread per node ----
-__global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec *packed, size_t total_nodes, int E, float s)
+// ---- load-time repack: one thread per node; writes the 16-byte and the 32-byte table ----
+__global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, NodeRec32 *packed32,
+                                              size_t total_slots, int D, int E, float s, int force_exact)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total_nodes) return;
+    // slot = tree * 2^D + h, h = 1-based heap index (slot h == 0 of each tree is unused and zeroed)
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= total_slots) return;
+    const size_t tree = slot >> D, h = slot & (((size_t)1 << D) - 1);
+    if (h == 0) {
+        NodeRec16 z16 = {{0u, 0u, 0u, 0u}};
+        NodeRec32 z32 = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
+        packed16[slot] = z16;
+        packed32[slot] = z32;
+        return;
+    }
+    const size_t i = tree * ((((size_t)1) << D) - 1) + (h - 1);
     const float *p = forest + i * (size_t)E;
-    NodeRec n;
+    NodeRec32 n;
     n.sux = s * p[0]; n.suy = s * p[1]; n.svx = s * p[2]; n.svy = s * p[3];
     n.thresh = p[4];
-    n.flags = node_flags(n.sux, n.suy, n.svx, n.svy, p[5], p[6]);
+    NodeRec16 h16 = encode_node(n.sux, n.suy, n.svx, n.svy, p[4], p[5], p[6]);
+    if (force_exact) h16.w[3] |= kFlagExact << 24;   // test knob: exercise the IEEE branch everywhere
+    n.flags = h16.w[3] >> 24;
     n.pad0 = n.pad1 = 0;
-    packed[i] = n;
+    packed16[slot] = h16;
+    packed32[slot] = n;
 }
 
 // ---- composite (tree_eval.cu:214-248): one lane per label pixel ----
@@ -555,10 +661,10 @@ struct LaunchGeom {
 };
 std::map<std::pair<const void *, int>, int> g_occ_cache;
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS>
-int launch_variant(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
+int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS>;
+    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, FULLROWS>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0;
     {
@@ -584,6 +690,13 @@ int launch_variant(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, a);
     return (int)hipGetLastError();
+}
+
+template <int BLOCK, bool PACKED, int CMAX, bool STATS>
+int launch_variant(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+{
+    return a.rows_per_wave == kMaxRowsPerWave ? launch_rows<BLOCK, PACKED, CMAX, STATS, true>(a, lds_bytes, cus, st)
+                                              : launch_rows<BLOCK, PACKED, CMAX, STATS, false>(a, lds_bytes, cus, st);
 }
 
 template <int BLOCK, bool PACKED, bool STATS>
@@ -618,7 +731,11 @@ int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void 
     return 0;
 }
 
-int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const NodeRec *packed,
+int g_halo = -1;
+int g_rows_per_wave = 0;
+int g_force_exact = 0;
+
+int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
                 const float *forest, int n_trees, int max_depth, int n_classes, const uint16_t *filter,
                 int filter_class, uint16_t *labels_out, int r, float s, int keep_if_no_leaf,
                 unsigned long long *stats, void *stream)
@@ -634,7 +751,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const No
 
     EvalArgs a;
     memset(&a, 0, sizeof(a));
-    a.depth = depth; a.forest = forest; a.packed = packed; a.filter = filter; a.labels = labels_out;
+    a.depth = depth; a.forest = forest; a.filter = filter; a.labels = labels_out;
     a.stats = stats;
     a.W = dim_x; a.H = dim_y; a.Wl = dim_x / r; a.Hl = dim_y / r; a.r = r;
     a.per_img_l = (uint32_t)a.Wl * (uint32_t)a.Hl;
@@ -644,26 +761,53 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const No
     a.filter_class = filter_class;
     a.keep_if_no_leaf = keep_if_no_leaf;
     a.s = s;
-
-    // top levels that fit the LDS budget: T * (2^K - 1) * 32 B <= budget
-    int K = 0;
-    const long long budget = lds_budget();
-    while (K < max_depth && (long long)n_trees * ((1ll << (K + 1)) - 1) * 32 + 16 <= budget) ++K;
-    a.lds_levels = K;
-    const int lds_bytes = (int)((long long)n_trees * ((1ll << K) - 1) * 32) + 16; // + queue mailbox
+    if (packed) {
+        const size_t slots = (size_t)n_trees << max_depth;   // 1-based heap slots, 2^D per tree
+        a.packed16 = reinterpret_cast<const NodeRec16 *>(packed);
+        a.packed32 = reinterpret_cast<const NodeRec32 *>(a.packed16 + slots);
+    }
 
     int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
     a.tiles_x = ((uint32_t)a.Wl + 63u) / 64u;
-    if (block != 256 && block != 512 && block != 1024) {
-        // small launches: smaller workgroups spread over more CUs
-        const long long groups = (long long)n_img * a.tiles_x * ((a.Hl + kChunkGroups - 1) / kChunkGroups);
-        block = groups >= 32ll * di.cus ? 1024 : (groups >= 16ll * di.cus ? 512 : 256);
+    if (block != 256 && block != 512 && block != 1024) block = 256;   // measured best on MI355X (profiles/)
+    // rows per wave: 4 amortises the tile staging; small launches (a single live frame) take fewer rows
+    // per wave so that every CU still gets several waves
+    int rpw = g_rows_per_wave > 0 ? g_rows_per_wave : env_int("RDF_ROWS_PER_WAVE", 0);
+    if (rpw < 1 || rpw > kMaxRowsPerWave) {
+        rpw = kMaxRowsPerWave;
+        const long long waves_wanted = 24ll * di.cus;
+        while (rpw > 1 && (long long)n_img * a.tiles_x * ((a.Hl + rpw - 1) / rpw) < waves_wanted) rpw >>= 1;
     }
-    const uint32_t tile_rows = (uint32_t)(block / 64) * kChunkGroups;
+    a.rows_per_wave = rpw;
+    const uint32_t tile_rows = (uint32_t)(block / 64) * (uint32_t)rpw;
     a.tiles_y = ((uint32_t)a.Hl + tile_rows - 1u) / tile_rows;
     const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
+
+    // ---- LDS plan: [node table: T*(2^K-1)*16 B][depth tile: th*twp*2 B][queue mailbox 16 B] ----
+    const long long budget = lds_budget();
+    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", kDefaultHalo);
+    long long tile_bytes = 0;
+    if (halo >= 0) {
+        const long long tw = 63ll * r + 1 + 2ll * halo;
+        const long long th = ((long long)tile_rows - 1) * r + 1 + 2ll * halo;
+        const long long twp = (tw + 1) & ~1ll;
+        tile_bytes = (th * twp * 2 + 15) & ~15ll;
+        if (tile_bytes <= budget / 2) {
+            a.halo = halo; a.tw = (int)tw; a.th = (int)th; a.twp = (int)twp;
+        } else {
+            tile_bytes = 0;   // tile does not fit (large labels_reduce): every probe reads global memory
+        }
+    }
+    int K = 0;
+    while (K < max_depth && (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 16 <= budget) ++K;
+    a.lds_levels = K;
+    const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
+    a.lds_tile_off = (uint32_t)node_bytes;
+    a.lds_mail_off = (uint32_t)(node_bytes + tile_bytes);
+    const int lds_bytes = (int)(node_bytes + tile_bytes + 16);
+
     a.sched = sched_slot(stream);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -707,20 +851,23 @@ int rdf_eval_tree(const uint16_t *depth, int n_img, int dim_x, int dim_y, const 
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth)
 {
     if (n_trees < 0 || max_depth < 0 || max_depth > 30) return 0;
-    return (size_t)n_trees * (size_t)((1ll << max_depth) - 1) * sizeof(NodeRec);
+    return ((size_t)n_trees << max_depth) * (sizeof(NodeRec16) + sizeof(NodeRec32));
 }
 
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes, float scale_factor,
                     void *packed, void *stream)
 {
     if (n_trees < 0 || max_depth < 0 || max_depth > 30 || n_classes < 0) return RDF_ERR_BAD_ARG;
-    const size_t total = (size_t)n_trees * (size_t)((1ll << max_depth) - 1);
-    if (total == 0) return RDF_OK;
+    if (max_depth > 27) return RDF_ERR_BAD_ARG;
+    const size_t total = (size_t)n_trees << max_depth;   // slots
+    if (total == 0 || max_depth == 0) return RDF_OK;
     if (!forest || !packed) return RDF_ERR_NULL_PTR;
     const size_t blocks = (total + 255) / 256;
     if (blocks >= (1ull << 31)) return RDF_ERR_TOO_LARGE;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       forest, reinterpret_cast<NodeRec *>(packed), total, 7 + 2 * n_classes, scale_factor);
+                       forest, reinterpret_cast<NodeRec16 *>(packed),
+                       reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total), total,
+                       max_depth, 7 + 2 * n_classes, scale_factor, g_force_exact);
     return (int)hipGetLastError();
 }
 
@@ -734,7 +881,7 @@ int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_
     if (!packed) // degenerate forest: nothing to walk, the unpacked path handles it
         return eval_common(depth, n_img, dim_x, dim_y, nullptr, forest, n_trees, max_depth, n_classes, filter,
                            filter_class, labels_out, labels_reduce, 1.0f, 0, nullptr, stream);
-    return eval_common(depth, n_img, dim_x, dim_y, reinterpret_cast<const NodeRec *>(packed), forest, n_trees,
+    return eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees,
                        max_depth, n_classes, filter, filter_class, labels_out, labels_reduce, 1.0f, 0, nullptr,
                        stream);
 }
@@ -786,6 +933,9 @@ int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, 
 void rdf_set_lds_budget_bytes(int bytes) { g_lds_budget = bytes; }
 void rdf_set_block_threads(int threads) { g_block_threads = threads; }
 void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
+void rdf_set_halo(int pixels) { g_halo = pixels; }
+void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
+void rdf_set_force_exact(int on) { g_force_exact = on; }
 
 int rdf_event_create(void **event)
 {

@@ -76,6 +76,18 @@ class Events:
             self.lib.rdf_event_destroy(e)
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def load_traffic(key):
     """HBM bytes per launch from a committed PMC run (profiles/roofline_traffic.json), or None."""
     p = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -171,7 +183,7 @@ def main():
                                f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
                                + ("labels gathered to rank 0 over RCCL inside the timed region" if world > 1 else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
-                   "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed32",
+                   "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
                    "pipeline_chunks": chunks, "sharding": f"frames x{world}, forest replicated"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -206,13 +218,13 @@ def main():
         if not a.no_cpu_baseline:
             from oracle import rdf_oracle  # the checker; never the thing measured as `value`
             got = labels.get()
-            cores = rdf_oracle.max_threads()
+            cores = min(host_cores(), rdf_oracle.max_threads())
             order = [i for pair in zip(range(0, F - F // 2), range(F - F // 2, F)) for i in pair]  # dense, live, dense, ...
             done, t_cpu, mism = 0, 0.0, 0
             for i in order:
                 want = np.full((1, H, W), 65535, np.uint16)
                 tc = time.perf_counter()
-                rdf_oracle.eval_forest(frames_np[i:i + 1], forest_np, want)
+                rdf_oracle.eval_forest(frames_np[i:i + 1], forest_np, want, n_threads=cores)
                 t_cpu += time.perf_counter() - tc
                 mism += int((want[0] != got[i]).sum())
                 done += 1

@@ -70,11 +70,13 @@ int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, 
                   const int32_t *cond, int n_cond, uint16_t *out, int32_t *bad_count, void *stream);
 
 /*
- * Load-time repack of a forest into 32-byte node records {s*ux, s*uy, s*vx, s*vy, thresh,
- * child flags}.  The reference has no counterpart: its "load" is the plain upload at
- * src/decision_tree.py:148-158.  The packed table depends on scale_factor and must be rebuilt
- * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes.
- * Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
+ * Load-time repack of a forest into a table of 16-byte hot records {int24 floor(s*u), int24
+ * floor(s*v), integer threshold, child flags} followed by a table of 32-byte exact records
+ * (fp32 s*u, s*v) that is read only for nodes whose numerators the integer form cannot
+ * represent.  The reference has no counterpart: its "load" is the plain upload at
+ * src/decision_tree.py:148-158.  The packed tables depend on scale_factor and must be rebuilt
+ * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes
+ * (48 per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
@@ -109,7 +111,10 @@ int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, 
 /* Tuning knobs (process-wide; 0 restores the default).  Not part of the reference surface. */
 void rdf_set_lds_budget_bytes(int bytes);
 void rdf_set_block_threads(int threads); /* 256, 512 or 1024 */
-void rdf_set_scheduler(int mode);        /* 1 dynamic chunk queue (default), 0 static round-robin, -1 env RDF_SCHED */
+void rdf_set_scheduler(int mode);        /* 1 dynamic tile queue (default), 0 static round-robin, -1 env RDF_SCHED */
+void rdf_set_rows_per_wave(int rows);    /* label rows per wave in a tile: 1, 2 or 4; 0 = choose by launch size */
+void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (16) */
+void rdf_set_force_exact(int on);        /* test knob: rdf_forest_pack flags every node for the IEEE-divide path */
 
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
 int rdf_event_create(void **event);

@@ -154,22 +154,70 @@ def test_random_sweep_bit_exact(cfg, path, rdf, evs, oracle):
     assert np.array_equal(got, want), f"{(got != want).sum()} of {want.size} pixels differ"
 
 
-@pytest.mark.parametrize("block,lds", [(256, 0), (256, 4096), (512, 81920), (1024, 163840), (1024, 0)])
-def test_launch_geometry_does_not_change_results(block, lds, rdf, gpu_runtime, evs, oracle):
+@pytest.mark.parametrize("block,lds,halo,sched", [(256, 0, 16, 1), (256, 4096, 0, 1), (512, 81920, 16, 0),
+                                                  (1024, 163840, 40, 1), (1024, 0, 3, 0), (256, 81920, 200, 1),
+                                                  (512, 40000, 7, 1)])
+def test_launch_geometry_does_not_change_results(block, lds, halo, sched, rdf, gpu_runtime, evs, oracle):
+    """Workgroup size, LDS budget (levels held in LDS), staged-tile halo (incl. 'tile does not fit')
+    and static vs dynamic tile queue are performance knobs only."""
     synth = rdf.synth
     forest = synth.forest(4, 12, 4, "trained")
     depth = synth.frames(["live", "dense", "live"], 700, 120, 200)
-    want = np.full(depth.shape, 65535, np.uint16)
-    oracle.eval_forest(depth, forest, want)
     lib = gpu_runtime.lib
     lib.rdf_set_block_threads(block)
     lib.rdf_set_lds_budget_bytes(lds if lds else 1)
+    lib.rdf_set_halo(halo)
+    lib.rdf_set_scheduler(sched)
     try:
-        for path in ("packed", "direct"):
-            assert np.array_equal(_gpu_forest(rdf, evs[path], depth, forest, 65535), want), (block, lds, path)
+        for r, s in ((1, 1.0), (2, 0.5), (5, 1.0)):
+            want = np.full((3, 120 // r, 200 // r), 65535, np.uint16)
+            oracle.eval_forest(depth, forest, want, r, scale_factor=s)
+            for path in ("packed", "direct"):
+                got = _gpu_forest(rdf, evs[path], depth, forest, 65535, r, s=s)
+                assert np.array_equal(got, want), (block, lds, halo, sched, path, r)
     finally:
         lib.rdf_set_block_threads(0)
         lib.rdf_set_lds_budget_bytes(0)
+        lib.rdf_set_halo(-1)
+        lib.rdf_set_scheduler(-1)
+
+
+ADVERSARIAL = [8388607.5, 8388607.0, 8388608.0, -8388608.0, -8388608.5, -8388607.5, 16777216.0, 3e9, -3e9, 1e-30,
+               -1e-30, 1e-45, -1e-45, 2.0 ** -87, -(2.0 ** -87), 2.0 ** -88, 11.999999, -11.999999, 23.999998,
+               0.99999994, -0.99999994, -1.0000001, 65534.0, 65533.996, 131067.99, 4000.0, 3999.9998, -4000.0,
+               0.0, -0.0, 0.5, -0.5, 1e38, -1e38, float("inf"), float("-inf"), float("nan"), 2.5e6, -2.5e6,
+               7999.9995, 12345.678, -12345.678, 1.17549435e-38, 8388606.5]
+
+
+@pytest.mark.parametrize("path", ["packed", "direct"])
+@pytest.mark.parametrize("force_exact", [0, 1])
+def test_adversarial_numerators_and_exact_fallback(path, force_exact, rdf, gpu_runtime, oracle):
+    """Offsets at the edges of what the 16-byte integer record can hold (|a| >= 2^23, denormals, inf, NaN,
+    values a hair below integers) must take the IEEE branch and still match; force_exact=1 sends EVERY
+    node of the packed path through that branch."""
+    rng = np.random.default_rng(77)
+    T, D, C = 4, 7, 4
+    n = (1 << D) - 1
+    forest = rdf.synth.forest(T, D, C, "trained", first_tree=50)
+    adv = np.array(ADVERSARIAL, dtype=np.float32)
+    pick = rng.random((T, n, 4)) < 0.5
+    forest[:, :, 0:4] = np.where(pick, adv[rng.integers(0, adv.size, size=(T, n, 4))], forest[:, :, 0:4])
+    forest[:, :, 4] = np.where(rng.random((T, n)) < 0.3,
+                               np.array([np.nan, np.inf, -np.inf, 65535.5, -65535.0, -65534.5, 0.5, -0.5, 7.0, 1e9],
+                                        dtype=np.float32)[rng.integers(0, 10, size=(T, n))], forest[:, :, 4])
+    depth = rdf.synth.frames(["dense", "live"], 40, 70, 90)
+    depth[0, :8, :8] = np.array([1, 2, 3, 7, 4000, 65534, 11, 12], dtype=np.uint16)[None, :]
+    lib = gpu_runtime.lib
+    lib.rdf_set_force_exact(force_exact)
+    try:
+        ev = rdf.DecisionTreeEvaluator(use_packed=(path == "packed"))
+        for r, s in ((1, 1.0), (2, 0.5), (1, 3.0)):
+            want = np.full((2, 70 // r, 90 // r), 65535, np.uint16)
+            oracle.eval_forest(depth, forest, want, r, scale_factor=s)
+            got = _gpu_forest(rdf, ev, depth, forest, 65535, r, s=s)
+            assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ (r={r}, s={s})"
+    finally:
+        lib.rdf_set_force_exact(0)
 
 
 @pytest.mark.parametrize("topology", ["full", "trained"])

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=1, help="launches per timing sample")
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--trees", type=int, default=4)
     ap.add_argument("--topology", default="full")
@@ -35,18 +36,21 @@ def main():
     depth = rdf.to_device(host)
     labels = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
     ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
-    combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]
+    combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]   # block:lds[:rows_per_wave[:halo]]
     res = {c: [] for c in combos}
     ref = None
     for r in range(a.rounds + 1):
         for c in combos:
             lib.rdf_set_block_threads(c[0])
             lib.rdf_set_lds_budget_bytes(c[1] if c[1] else 1)
+            lib.rdf_set_rows_per_wave(c[2] if len(c) > 2 else 0)
+            lib.rdf_set_halo(c[3] if len(c) > 3 else -1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ev.get_labels_forest(forest, depth, labels)
+            for _ in range(a.reps):
+                ev.get_labels_forest(forest, depth, labels)
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt = (time.perf_counter() - t0) / a.reps
             if r:
                 res[c].append(dt * 1e3)
             else:
@@ -56,7 +60,7 @@ def main():
     npx = a.frames * 480 * 848
     for c in combos:
         v = np.array(res[c])
-        print(f"block {c[0]:5d} lds {c[1]:7d}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
+        print(f"block {c[0]:5d} lds {c[1]:7d} rpw {c[2] if len(c) > 2 else 0} halo {c[3] if len(c) > 3 else -1:3d}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
               f"{npx / np.median(v) / 1e3:8.1f} Mpix/s", flush=True)
 
 
