@@ -215,6 +215,23 @@ def main():
                                     "ms_per_frame_wall": round(wall1 * 1e3, 4), "ms_per_frame_device": round(dev1 * 1e3, 4),
                                     "frame": "dense #0", "launches": n1}
 
+        # ---- host-buffer variant: pinned H2D of the frames + kernel + D2H of the labels (never `value`) ----
+        pin_in = torch.from_numpy(frames_np.view(np.int16).reshape(-1)).pin_memory()
+        pin_out = torch.empty(F * H * W, dtype=torch.int16).pin_memory()
+        d_t, l_t = depth.torch_bytes().view(torch.int16), labels.torch_bytes().view(torch.int16)
+        for rep in range(4):
+            if rep == 1:
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+            d_t.copy_(pin_in, non_blocking=True)
+            ev.get_labels_forest(forest, depth, labels)
+            pin_out.copy_(l_t, non_blocking=True)
+        torch.cuda.synchronize()
+        wall_p = (time.perf_counter() - tp) / 3
+        out["pcie_inclusive"] = {"value": round(F * H * W / wall_p / 1e6, 2), "unit": "Mpix/s",
+                                 "ms_per_step": round(wall_p * 1e3, 3),
+                                 "what": "pinned H2D of the batch + kernel + D2H of the labels, serial on one stream"}
+
         if not a.no_cpu_baseline:
             from oracle import rdf_oracle  # the checker; never the thing measured as `value`
             got = labels.get()
