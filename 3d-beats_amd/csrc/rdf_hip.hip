@@ -194,24 +194,41 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
     return n;
 }
 
-// Depth value at (x, y) of the current image: from the staged LDS tile when the coordinate falls
-// inside it (cells outside the image already hold 65535), else from global memory with the per-axis
-// bounds check of cu_utils.hpp:79-86.  `depth_b` is the wave-uniform batch base; offsets are 32-bit
-// byte offsets (a call addresses < 2^31 pixels).
-__device__ __forceinline__ int probe(const uint16_t *tile, int tx0, int ty0, int tw, int th, int twp,
-                                     const char *depth_b, uint32_t img_boff, int x, int y, int W, int H)
+// A depth probe at (x, y) of the current image is answered by the staged LDS tile when the coordinate
+// falls inside it (cells outside the image already hold 65535), else by global memory with the
+// per-axis bounds check of cu_utils.hpp:79-86.  Both loads are ISSUED for every lane -- a lane that
+// does not need one of them reads a fixed safe address, which costs one shared cache line / LDS
+// word per wave -- so that all probes of a level are in flight together and nothing waits inside
+// a divergent branch.  `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets
+// (a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is < 2^24 when used).
+struct ProbeCtx {
+    const uint16_t *tile;   // LDS
+    const char *depth_b;
+    uint32_t img_boff;
+    int tx0, ty0, tw, th, twp, W, H;
+};
+
+struct Probe {
+    uint32_t lds_v, glb_v;   // the two candidate values
+    bool in_tile, inb;
+};
+
+__device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int x, int y)
 {
-    const int cx = x - tx0, cy = y - ty0;
-    uint32_t v;
-    if ((uint32_t)cx < (uint32_t)tw && (uint32_t)cy < (uint32_t)th) {
-        v = tile[cy * twp + cx];
-    } else {
-        const bool inb = (uint32_t)x < (uint32_t)W && (uint32_t)y < (uint32_t)H;
-        const uint32_t off = inb ? img_boff + (((uint32_t)y * (uint32_t)W + (uint32_t)x) << 1) : img_boff;
-        v = *reinterpret_cast<const uint16_t *>(depth_b + off);
-        v = inb ? v : kNoPixel;
-    }
-    return (int)v;
+    Probe p;
+    const uint32_t cx = (uint32_t)(x - c.tx0), cy = (uint32_t)(y - c.ty0);
+    p.in_tile = cx < (uint32_t)c.tw && cy < (uint32_t)c.th;
+    p.inb = (uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H;
+    const uint32_t li = p.in_tile ? __umul24(cy, (uint32_t)c.twp) + cx : 0u;
+    const uint32_t go = (p.inb && !p.in_tile) ? (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1 : 0u;
+    p.lds_v = c.tile[li];
+    p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
+    return p;
+}
+
+__device__ __forceinline__ int probe_value(const Probe &p)
+{
+    return (int)(p.in_tile ? p.lds_v : (p.inb ? p.glb_v : kNoPixel));
 }
 
 // FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
@@ -279,6 +296,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         const int tx0 = (int)(tx * 64u) * a.r - a.halo;
         const int ty0 = (int)(ty * tile_rows) * a.r - a.halo;
 
+        const ProbeCtx pc = {lds_tile, depth_b, img_boff, tx0, ty0, tw, th, twp, a.W, a.H};
         // ---- stage depth [ty0, ty0+th) x [tx0, tx0+tw) into LDS; outside the image = 65535 ----
         if (tw > 0) {
             for (int row = (int)wave; row < th; row += (int)kWaves) {
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                     uint32_t v = kNoPixel;
                     if (row_in && (uint32_t)gx < (uint32_t)a.W)
                         v = *reinterpret_cast<const uint16_t *>(
-                            depth_b + (img_boff + (((uint32_t)gy * (uint32_t)a.W + (uint32_t)gx) << 1)));
+                            depth_b + (img_boff + ((__umul24((uint32_t)gy, (uint32_t)a.W) + (uint32_t)gx) << 1)));
                     lds_tile[row * twp + col] = (uint16_t)v;
                 }
             }
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             if (a.filter_class != -1) {
                 if ((int)a.filter[i] != a.filter_class) continue;
             }
-            const uint32_t d = (uint32_t)probe(lds_tile, tx0, ty0, tw, th, twp, depth_b, img_boff, x, y, a.W, a.H);
+            const uint32_t d = (uint32_t)probe_value(probe_issue(pc, x, y));
             if (d == 0u || d == kNoPixel) continue;
             const float df = (float)d;
             // refined reciprocal shared by every divide of this pixel (fast path only)
@@ -420,27 +438,24 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             }
                         }
 
-                        int pu[kGroup], pv[kGroup];
+                        Probe qu[kGroup], qv[kGroup];
 #pragma unroll
                         for (int k = 0; k < kGroup; ++k) {
-                            pu[k] = probe(lds_tile, tx0, ty0, tw, th, twp, depth_b, img_boff, ux[k], uy[k], a.W, a.H);
-                            pv[k] = probe(lds_tile, tx0, ty0, tw, th, twp, depth_b, img_boff, vx[k], vy[k], a.W, a.H);
+                            qu[k] = probe_issue(pc, ux[k], uy[k]);
+                            qv[k] = probe_issue(pc, vx[k], vy[k]);
                         }
 
+                        // ---- decide (tree_eval.cu:107-121), branch-free ----
 #pragma unroll
                         for (int k = 0; k < kGroup; ++k) {
-                            if (act[k]) {
-                                if (STATS && c0 == 0) st_lv++;
-                                const bool left = (pu[k] - pv[k]) < n[k].t;
-                                const bool cont = (n[k].flags & (left ? kFlagLeft : kFlagRight)) != 0u;
-                                const uint32_t side = left ? 0u : 1u;
-                                if (cont) {
-                                    h[k] = h[k] * 2u + side;
-                                } else {
-                                    leaf[k] = (int)(((h[k] - 1u) << 1) | side);
-                                    act[k] = false;
-                                }
-                            }
+                            if (STATS && c0 == 0) st_lv += act[k] ? 1u : 0u;
+                            const bool left = (probe_value(qu[k]) - probe_value(qv[k])) < n[k].t;
+                            const bool cont = (n[k].flags & (left ? kFlagLeft : kFlagRight)) != 0u;
+                            const uint32_t side = left ? 0u : 1u;
+                            const bool stop = act[k] && !cont;
+                            leaf[k] = stop ? (int)(((h[k] - 1u) << 1) | side) : leaf[k];
+                            act[k] = act[k] && cont;
+                            h[k] = act[k] ? h[k] * 2u + side : h[k];
                         }
                     }
 
