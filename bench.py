@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--classes", type=int, default=4)
     ap.add_argument("--topology", default="full", choices=["full", "trained"])
-    ap.add_argument("--chunks", type=int, default=0, help="eval/gather pipeline chunks per step (0: 1 at N=1, 4 at N>1)")
+    ap.add_argument("--chunks", type=int, default=0, help="eval/gather pipeline chunks per step (0: 1 at N=1, 8 at N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
@@ -131,7 +131,7 @@ def main():
     ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
     if not a.unpacked:
         forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
-    chunks = a.chunks or (1 if world == 1 else 4)
+    chunks = a.chunks or (1 if world == 1 else 8)
     sharded = dmod.ShardedForestEvaluator(ev, forest, F, (H, W), n_chunks=chunks)
 
     # ---- algorithmic bytes of one step, from the visit counters of the same walk ----
@@ -169,6 +169,22 @@ def main():
     evs.destroy()
     assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"
 
+    # ---- N>1: did rank 0 really receive every rank's label maps?  (checksum of checksums) ----
+    gather_check = None
+    if world > 1:
+        mine = labels.torch_bytes().view(torch.int16).to(torch.int64)
+        sums = torch.stack([mine.sum(), (mine * (torch.arange(mine.numel(), device=mine.device) % 8191)).sum()])
+        allsums = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(allsums, sums)
+        if rank == 0:
+            got = sharded.result()
+            ok = True
+            for g in range(world):
+                part = got[g * F:(g + 1) * F].torch_bytes().view(torch.int16).to(torch.int64)
+                chk = torch.stack([part.sum(), (part * (torch.arange(part.numel(), device=part.device) % 8191)).sum()])
+                ok = ok and bool(torch.equal(chk, allsums[g]))
+            gather_check = "ok" if ok else "MISMATCH"
+
     pix_per_step = world * F * H * W
     value = pix_per_step * a.steps / elapsed / 1e6
     kern_avg_s = float(np.mean(kern_ms)) / 1e3
@@ -184,7 +200,8 @@ def main():
                                + ("labels gathered to rank 0 over RCCL inside the timed region" if world > 1 else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
                    "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
-                   "pipeline_chunks": chunks, "sharding": f"frames x{world}, forest replicated"},
+                   "pipeline_chunks": chunks, "sharding": f"frames x{world}, forest replicated",
+                   "gather_check": gather_check},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": load_traffic(f"F{F}_T{T}_D{D}_C{C}_{a.topology}"),
@@ -214,6 +231,26 @@ def main():
         out["cfg2_single_frame"] = {"value": round(H * W / wall1 / 1e6, 2), "unit": "Mpix/s",
                                     "ms_per_frame_wall": round(wall1 * 1e3, 4), "ms_per_frame_device": round(dev1 * 1e3, 4),
                                     "frame": "dense #0", "launches": n1}
+
+        # ---- config 3: 2-layer stack through LayeredDecisionForest.run (run_live_layered.py:126), r = 2 ----
+        cfg3 = {"layers": [{"model": forest}, {"model": forest, "filter_model": 0, "filter_model_class": 3}],
+                "conditions": [[0, 1], [0, 2], [1, 3], [0, 3], [0, 4], [0, 5], [0, 6]],
+                "label_colors": [[0, 0, 0, 255]] * 6}
+        lf = rdf.LayeredDecisionForest(cfg3, (H, W), 2)
+        dbuf, lbuf = rdf.GpuBuffer((H, W), np.uint16), rdf.GpuBuffer((H // 2, W // 2), np.uint16)
+        dbuf.cu().set(frames_np[F - 1])   # a live-like frame
+        for _ in range(10):
+            lf.run(dbuf, lbuf, 1.0)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(100):
+            lf.run(dbuf, lbuf, 1.0)
+        torch.cuda.synchronize()
+        w3 = (time.perf_counter() - t3) / 100
+        out["cfg3_layered_run"] = {"ms_per_frame_wall": round(w3 * 1e3, 4), "value": round(H * W / w3 / 1e6, 2),
+                                   "unit": "Mpix/s", "what": "LayeredDecisionForest.run, 2 layers (second filtered on "
+                                   "class 3 of the first), labels_reduce 2, one live-like 848x480 frame: 3 fills + 2 "
+                                   "forest launches + composite"}
 
         # ---- host-buffer variant: pinned H2D of the frames + kernel + D2H of the labels (never `value`) ----
         pin_in = torch.from_numpy(frames_np.view(np.int16).reshape(-1)).pin_memory()

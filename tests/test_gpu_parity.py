@@ -293,3 +293,16 @@ def test_bad_arguments_are_rejected(rdf, gpu_runtime):
     assert lib.rdf_eval_forest(d.ptr, 70000, 1 << 15, 1, f.ptr, 1, 1, 1, None, -1, d.ptr, 1, 1.0, st) == -3
     assert lib.rdf_eval_forest(d.ptr, 0, 4, 4, f.ptr, 1, 1, 1, None, -1, d.ptr, 1, 1.0, st) == 0        # empty batch
     assert lib.rdf_eval_forest(d.ptr, 1, 4, 4, f.ptr, 1, 1, 1, None, -1, d.ptr, 8, 1.0, st) == 0        # r > dims
+
+
+def test_config5_shape_bit_exact(rdf, evs, oracle):
+    """BASELINE config 5's shape: 1280x720 frames, 8-tree depth-22 forest (1.875 GiB; packed tables 3 GiB).
+    Two frames so that the oracle finishes in seconds."""
+    synth = rdf.synth
+    forest = synth.forest(8, 22, 4, "full")
+    depth = synth.frames(["dense", "live"], 5000, 720, 1280)
+    want = np.full(depth.shape, 65535, np.uint16)
+    oracle.eval_forest(depth, forest, want)
+    got = _gpu_forest(rdf, evs["packed"], depth, forest, 65535)
+    assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ"
+    del forest
