@@ -196,10 +196,9 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
 
 // A depth probe at (x, y) of the current image is answered by the staged LDS tile when the coordinate
 // falls inside it (cells outside the image already hold 65535), else by global memory with the
-// per-axis bounds check of cu_utils.hpp:79-86.  Both loads are ISSUED for every lane -- a lane that
-// does not need one of them reads a fixed safe address, which costs one shared cache line / LDS
-// word per wave -- so that all probes of a level are in flight together and nothing waits inside
-// a divergent branch.  `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets
+// per-axis bounds check of cu_utils.hpp:79-86.  The loads are only ISSUED here; their values are
+// consumed after all probes of the level have been issued, so every probe of a level is in flight
+// together and nothing waits inside a divergent branch (an earlier version waited vmcnt(0) per probe).  `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets
 // (a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is < 2^24 when used).
 struct ProbeCtx {
     const uint16_t *tile;   // LDS
@@ -220,9 +219,12 @@ __device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int x, int y)
     p.in_tile = cx < (uint32_t)c.tw && cy < (uint32_t)c.th;
     p.inb = (uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H;
     const uint32_t li = p.in_tile ? __umul24(cy, (uint32_t)c.twp) + cx : 0u;
-    const uint32_t go = (p.inb && !p.in_tile) ? (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1 : 0u;
     p.lds_v = c.tile[li];
-    p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
+    p.glb_v = 0u;
+    if (p.inb && !p.in_tile) {   // only far lanes touch global memory; the value is consumed after the branch
+        const uint32_t go = (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1;
+        p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
+    }
     return p;
 }
 

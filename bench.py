@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
+                    "rehearse the control flow with several ranks on one GPU)")
     return ap.parse_args()
 
 
@@ -109,12 +111,15 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N (N>1) must be launched with torch.distributed.run --nproc-per-node N")
         a.gpus = world
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     rdf = importlib.import_module("3d-beats_amd")
     dmod = importlib.import_module("3d-beats_amd.distributed")
@@ -197,7 +202,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{F} x {W}x{H} depth frames per GPU per step (config 4 shard = config 2 frame x {F}; "
                                f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
-                               + ("labels gathered to rank 0 over RCCL inside the timed region" if world > 1 else "1 GPU"),
+                               + (f"labels gathered to rank 0 ({a.backend}) inside the timed region" if world > 1 else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
                    "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
                    "pipeline_chunks": chunks, "sharding": f"frames x{world}, forest replicated",
