@@ -345,42 +345,43 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                 for (int c = 0; c < CMAX; ++c) pdf[c] = 0.0f;
 
                 for (int kb = 0; kb < a.T; kb += kGroup) {
-                    uint32_t h[kGroup];     // 1-based heap index of the current node
-                    int leaf[kGroup];
-                    bool act[kGroup];
+                    // Walk state, one word per tree: while walking, the 1-based heap index of the current node
+                    // (< 2^31); once a leaf is reached, kDone | ((node - 1) * 2 + side); kIdle for tree slots
+                    // beyond T.  "Still walking" is simply (int)h > 0.
+                    constexpr uint32_t kDone = 0x80000000u, kIdle = 0xFFFFFFFFu;
+                    uint32_t h[kGroup];
 #pragma unroll
-                    for (int k = 0; k < kGroup; ++k) {
-                        h[k] = 1u;
-                        leaf[k] = -1;
-                        act[k] = (kb + k) < a.T;
-                    }
+                    for (int k = 0; k < kGroup; ++k) h[k] = (kb + k) < a.T ? 1u : kIdle;
 
                     for (int j = 0; j < a.D; ++j) {
                         bool any = false;
 #pragma unroll
-                        for (int k = 0; k < kGroup; ++k) any |= act[k];
+                        for (int k = 0; k < kGroup; ++k) any |= (int)h[k] > 0;
                         if (!__any(any)) break;
 
                         const bool in_lds = j < K;
                         Node n[kGroup];
+                        uint32_t hn[kGroup];   // node to fetch: a finished or idle slot re-reads the root (cheap, discarded)
+#pragma unroll
+                        for (int k = 0; k < kGroup; ++k) hn[k] = (int)h[k] > 0 ? h[k] : 1u;
                         if (in_lds) {
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
                                 const uint32_t tk = (uint32_t)min(kb + k, a.T - 1);   // wave-uniform
-                                n[k] = decode_node(lds_nodes[tk * lds_pitch + h[k]]);
+                                n[k] = decode_node(lds_nodes[tk * lds_pitch + hn[k]]);
                             }
                         } else if (PACKED) {
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
                                 const int tk = min(kb + k, a.T - 1);
                                 const char *base = reinterpret_cast<const char *>(a.packed16 + ((size_t)tk << a.D));
-                                n[k] = decode_node(*reinterpret_cast<const uint4 *>(base + h[k] * 16u));
+                                n[k] = decode_node(*reinterpret_cast<const uint4 *>(base + hn[k] * 16u));
                             }
                         } else {
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
                                 const int tk = min(kb + k, a.T - 1);
-                                const float *p = a.forest + ((size_t)tk * (size_t)a.nodes + (h[k] - 1u)) * (size_t)a.E;
+                                const float *p = a.forest + ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
                                 n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1]; n[k].bx = a.s * p[2]; n[k].by = a.s * p[3];
                                 n[k].t = thresh_to_int(p[4]);
                                 n[k].flags = child_flags(p[5], p[6]) | kFlagExact;   // fp32 numerators: IEEE divide
@@ -402,11 +403,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                                         const int tk = min(kb + k, a.T - 1);
                                         if (PACKED) {
                                             const float4 e = *reinterpret_cast<const float4 *>(
-                                                a.packed32 + ((size_t)tk << a.D) + h[k]);
+                                                a.packed32 + ((size_t)tk << a.D) + hn[k]);
                                             n[k].ax = e.x; n[k].ay = e.y; n[k].bx = e.z; n[k].by = e.w;
                                         } else {
                                             const float *p = a.forest +
-                                                ((size_t)tk * (size_t)a.nodes + (h[k] - 1u)) * (size_t)a.E;
+                                                ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
                                             n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1];
                                             n[k].bx = a.s * p[2]; n[k].by = a.s * p[3];
                                         }
@@ -450,26 +451,26 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                         // ---- decide (tree_eval.cu:107-121), branch-free ----
 #pragma unroll
                         for (int k = 0; k < kGroup; ++k) {
-                            if (STATS && c0 == 0) st_lv += act[k] ? 1u : 0u;
-                            const bool left = (probe_value(qu[k]) - probe_value(qv[k])) < n[k].t;
-                            const bool cont = (n[k].flags & (left ? kFlagLeft : kFlagRight)) != 0u;
-                            const uint32_t side = left ? 0u : 1u;
-                            const bool stop = act[k] && !cont;
-                            leaf[k] = stop ? (int)(((h[k] - 1u) << 1) | side) : leaf[k];
-                            act[k] = act[k] && cont;
-                            h[k] = act[k] ? h[k] * 2u + side : h[k];
+                            const bool walking = (int)h[k] > 0;
+                            if (STATS && c0 == 0) st_lv += walking ? 1u : 0u;
+                            const uint32_t side = (probe_value(qu[k]) - probe_value(qv[k])) < n[k].t ? 0u : 1u;
+                            const bool cont = ((n[k].flags >> side) & 1u) != 0u;      // kFlagLeft = bit 0, kFlagRight = bit 1
+                            const uint32_t child = h[k] * 2u + side;                   // also (node-1)*2 + side + 2
+                            const uint32_t next = cont ? child : child + (kDone - 2u);
+                            h[k] = walking ? next : h[k];
                         }
                     }
 
                     // leaf PDFs, strictly in tree order (canonical sum order)
 #pragma unroll
                     for (int k = 0; k < kGroup; ++k) {
-                        if (leaf[k] >= 0) {
+                        if ((int)h[k] < 0 && h[k] != kIdle) {
+                            const uint32_t leaf = h[k] & ~kDone;   // (node - 1) * 2 + side
                             any_leaf = true;
                             if (STATS && c0 == 0) st_lf++;
                             const float *pp = a.forest +
-                                ((size_t)(kb + k) * (size_t)a.nodes + (uint32_t)(leaf[k] >> 1)) * (size_t)a.E +
-                                7 + (leaf[k] & 1) * a.C + c0;
+                                ((size_t)(kb + k) * (size_t)a.nodes + (leaf >> 1)) * (size_t)a.E +
+                                7 + (leaf & 1u) * a.C + c0;
 #pragma unroll
                             for (int c = 0; c < CMAX; ++c) {
                                 if (c0 + c < a.C) pdf[c] = pdf[c] + pp[c];
