@@ -103,6 +103,7 @@ struct EvalArgs {
     uint32_t lds_mail_off;
     int filter_class;
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
+    int fill_untouched;    // fused pre-fill: write 65535 to every label pixel that is not evaluated
     float s;
 };
 
@@ -299,6 +300,27 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         const int ty0 = (int)(ty * tile_rows) * a.r - a.halo;
 
         const ProbeCtx pc = {lds_tile, depth_b, img_boff, tx0, ty0, tw, th, twp, a.W, a.H};
+
+        // ---- empty tile?  (live frames are mostly background.)  Every wave looks at the centre depths of its
+        // own rows straight from global memory; a tile without a single pixel to evaluate is not staged.
+        // Throughput shape only: with one row per wave the extra round trip costs more than it saves ----
+        if (FULLROWS && tw > 0) {
+            bool mine = false;
+            for (int sub = 0; sub < rows_per_wave; ++sub) {
+                const int ly = (int)(ty * tile_rows + (uint32_t)sub * kWaves + wave);
+                if (ly < a.Hl && lx < a.Wl) {
+                    const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
+                    const uint32_t d = *reinterpret_cast<const uint16_t *>(
+                        depth_b + (img_boff + ((__umul24((uint32_t)(ly * a.r), (uint32_t)a.W) + (uint32_t)(lx * a.r)) << 1)));
+                    bool ok = d != 0u && d != kNoPixel;
+                    if (ok && a.filter_class != -1) ok = (int)a.filter[i] == a.filter_class;
+                    mine |= ok;
+                    if (!ok && a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
+                }
+            }
+            if (!__syncthreads_or(mine ? 1 : 0)) continue;   // block-uniform
+        }
+
         // ---- stage depth [ty0, ty0+th) x [tx0, tx0+tw) into LDS; outside the image = 65535 ----
         if (tw > 0) {
             for (int row = (int)wave; row < th; row += (int)kWaves) {
@@ -323,11 +345,16 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
             const int x = lx * a.r, y = ly * a.r;
 
-            if (a.filter_class != -1) {
-                if ((int)a.filter[i] != a.filter_class) continue;
+            // Pixels the reference kernel returns early on are left untouched (tree_eval.cu:81-89) -- unless the
+            // caller asked for the fused pre-fill, which stores what its separate fill(65535) would have left.
+            bool skip = false;
+            if (a.filter_class != -1) skip = (int)a.filter[i] != a.filter_class;
+            uint32_t d = 0u;
+            if (!skip) d = (uint32_t)probe_value(probe_issue(pc, x, y));
+            if (skip || d == 0u || d == kNoPixel) {
+                if (a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
+                continue;
             }
-            const uint32_t d = (uint32_t)probe_value(probe_issue(pc, x, y));
-            if (d == 0u || d == kNoPixel) continue;
             const float df = (float)d;
             // refined reciprocal shared by every divide of this pixel (fast path only)
             const float r0 = __builtin_amdgcn_rcpf(df);
@@ -489,7 +516,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             }
 
             if (STATS) st_px++;
-            if (a.keep_if_no_leaf && !any_leaf) continue;
+            if (a.keep_if_no_leaf && !any_leaf) {
+                if (a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
+                continue;
+            }
             a.labels[i] = (uint16_t)best_c;
         }
     }
@@ -549,19 +579,18 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
 
 // ---- composite (tree_eval.cu:214-248): one lane per label pixel ----
 __global__ __launch_bounds__(256) void k_composite(const uint16_t *const *imgs, int n_images, uint32_t n_px,
-                                                   const int2 *cond, int n_cond, uint16_t *out, int32_t *bad)
+                                                   const int2 *cond, int n_cond, uint16_t *out, int32_t *bad,
+                                                   int fill_untouched)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_px) return;
     long long off = 0;
+    bool invalid = true;   // fell off the last image (tree_eval.cu:246-247)
     for (int i = 0; i < n_images; ++i) {
         const uint32_t l = imgs[i][p];
-        if (l == 0u || l == kNoPixel) return;
+        if (l == 0u || l == kNoPixel) { invalid = false; break; }   // :235 -- pixel keeps its pre-fill
         const long long e = off + (long long)l - 1;
-        if (e < 0 || e >= n_cond) {
-            if (bad) atomicAdd(bad, 1);
-            return;
-        }
+        if (e < 0 || e >= n_cond) break;
         const int2 tv = cond[e];
         if (tv.x == 0) {
             out[p] = (uint16_t)tv.y;
@@ -569,7 +598,8 @@ __global__ __launch_bounds__(256) void k_composite(const uint16_t *const *imgs, 
         }
         off = tv.y;
     }
-    if (bad) atomicAdd(bad, 1);
+    if (invalid && bad) atomicAdd(bad, 1);
+    if (fill_untouched) out[p] = (uint16_t)kNoPixel;
 }
 
 __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *dst, size_t n, uint16_t v)
@@ -756,7 +786,7 @@ int g_force_exact = 0;
 int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
                 const float *forest, int n_trees, int max_depth, int n_classes, const uint16_t *filter,
                 int filter_class, uint16_t *labels_out, int r, float s, int keep_if_no_leaf,
-                unsigned long long *stats, void *stream)
+                unsigned long long *stats, void *stream, int fill_untouched = 0)
 {
     int rc = check_common(depth, n_img, dim_x, dim_y, forest, n_trees, max_depth, n_classes, labels_out, r);
     if (rc == 1) return RDF_OK;
@@ -778,6 +808,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     a.nodes = (int)((1ll << max_depth) - 1);
     a.filter_class = filter_class;
     a.keep_if_no_leaf = keep_if_no_leaf;
+    a.fill_untouched = fill_untouched;
     a.s = s;
     if (packed) {
         const size_t slots = (size_t)n_trees << max_depth;   // 1-based heap slots, 2^D per tree
@@ -915,7 +946,41 @@ int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, 
     const unsigned blocks = (unsigned)((n_px + 255) / 256);
     hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        label_images, n_images, (uint32_t)n_px, reinterpret_cast<const int2 *>(cond), n_cond, out,
-                       bad_count);
+                       bad_count, 0);
+    return (int)hipGetLastError();
+}
+
+int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers, const void *const *packed,
+                    const float *const *forests, const int *n_trees, const int *max_depth, const int *n_classes,
+                    const int *filter_layer, const int *filter_class, uint16_t *const *layer_labels,
+                    const uint16_t *const *layer_labels_dev_table, const int32_t *cond, int n_cond,
+                    uint16_t *composite_out, int32_t *bad_count, int labels_reduce, float scale_factor,
+                    void *stream)
+{
+    if (n_layers < 0 || dim_x < 0 || dim_y < 0 || labels_reduce < 1 || n_cond < 0) return RDF_ERR_BAD_ARG;
+    if (n_layers > 0 && (!forests || !n_trees || !max_depth || !n_classes || !filter_layer || !filter_class ||
+                         !layer_labels || !layer_labels_dev_table))
+        return RDF_ERR_NULL_PTR;
+    if (!composite_out) return RDF_ERR_NULL_PTR;
+    for (int i = 0; i < n_layers; ++i) {
+        const int fl = filter_layer[i];
+        if (fl >= n_layers) return RDF_ERR_BAD_ARG;
+        const uint16_t *filt = fl >= 0 ? layer_labels[fl] : nullptr;
+        const void *pk = packed ? packed[i] : nullptr;
+        if (pk && max_depth[i] > 27) pk = nullptr;
+        const int rc = eval_common(depth, 1, dim_x, dim_y, pk, forests[i], n_trees[i], max_depth[i], n_classes[i],
+                                   filt, fl >= 0 ? filter_class[i] : -1, layer_labels[i], labels_reduce,
+                                   pk ? 1.0f : scale_factor, 0, nullptr, stream, /*fill_untouched=*/1);
+        if (rc != RDF_OK) return rc;
+    }
+    const int lw = dim_x / labels_reduce, lh = dim_y / labels_reduce;
+    const long long n_px = (long long)lw * lh;
+    if (n_px == 0) return RDF_OK;
+    if (n_cond > 0 && !cond) return RDF_ERR_NULL_PTR;
+    const unsigned blocks = (unsigned)((n_px + 255) / 256);
+    hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       layer_labels_dev_table, n_layers, (uint32_t)n_px, reinterpret_cast<const int2 *>(cond), n_cond,
+                       composite_out, bad_count, 1);
     return (int)hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray, device_ptr, get_runtime
 from .engine.buffer import GpuBuffer
-from .util import MAX_UINT16, sizeof_fmt  # noqa: F401  (re-exported like the reference module)
+from .util import MAX_UINT16  # noqa: F401  (re-exported like the reference module)
 
 _PIX_LIMIT = (1 << 31) - 1  # one C-ABI call addresses < 2^31 depth pixels (RDF_ERR_TOO_LARGE)
 
@@ -110,8 +110,10 @@ class LayeredDecisionForest:
         cfg['root'] = os.path.dirname(os.path.abspath(config_filename))
         return LayeredDecisionForest(cfg, depth_dims, labels_reduce)
 
-    def __init__(self, cfg, depth_dims, labels_reduce):
+    def __init__(self, cfg, depth_dims, labels_reduce, fused=True):
         self.eval = DecisionTreeEvaluator()
+        self.fused = fused          # run() through rdf_layered_run (one call) or step by step like the reference
+        self._fused_args = None
 
         self.depth_dims = tuple(depth_dims)  # y,x !!
         self.labels_reduce = labels_reduce
@@ -155,32 +157,58 @@ class LayeredDecisionForest:
         self.label_colors.cu().set(label_colors)
 
     def run(self, depth_image, labels_image, scale_factor=1.):
+        """Per-frame entry of the live apps (run_live_layered.py:126, 3d_bz.py:389-437): every label buffer ends
+        up 65535 where nothing was classified, layer i holds forest i's labels, labels_image the composite."""
+        if self.fused:
+            return self._run_fused(depth_image, labels_image, scale_factor)
+
         labels_image.cu().fill(MAX_UINT16)
-        for i in self.label_images:
-            i.cu().fill(MAX_UINT16)
+        for buf in self.label_images:
+            buf.cu().fill(MAX_UINT16)
 
-        # first dim: image id. only one image!
-        depth_img_dims = (1,) + self.depth_dims
-        label_img_dims = (1,) + self.labels_dims
+        # one image per call: add the leading image axis
+        depth_3d = depth_image.cu().reshape((1,) + self.depth_dims)
+        label_shape = (1,) + self.labels_dims
+        for (forest, filter_model, filter_model_class), out_buf in zip(self.m, self.label_images):
+            filt = self.label_images[filter_model].cu().reshape(label_shape) if filter_model is not None else None
+            self.eval.get_labels_forest(forest, depth_3d, out_buf.cu().reshape(label_shape),
+                                        labels_reduce=self.labels_reduce, filter_images=filt,
+                                        filter_images_class=filter_model_class, scale_factor=scale_factor)
 
-        for i in range(self.num_models):
-            m, filter_model, filter_model_class = self.m[i]
-            single_labels_image = self.label_images[i]
-            self.eval.get_labels_forest(
-                m,
-                depth_image.cu().reshape(depth_img_dims),
-                single_labels_image.cu().reshape(label_img_dims),
-                labels_reduce=self.labels_reduce,
-                filter_images=self.label_images[filter_model].cu().reshape(label_img_dims) if (filter_model is not None) else None,
-                filter_images_class=filter_model_class,
-                scale_factor=scale_factor)
+        self.eval.make_composite_labels_image(self.labels_images_ptrs_cu.cu(), self.labels_dims[1], self.labels_dims[0],
+                                              self.labels_conditions_cu.cu(), labels_image.cu().reshape(label_shape))
 
-        self.eval.make_composite_labels_image(
-            self.labels_images_ptrs_cu.cu(),
-            self.labels_dims[1],
-            self.labels_dims[0],
-            self.labels_conditions_cu.cu(),
-            labels_image.cu().reshape(label_img_dims))
+    def _run_fused(self, depth_image, labels_image, scale_factor):
+        """Same result through ONE C-ABI call (rdf_layered_run): the three fills are fused into the kernels."""
+        import ctypes
+        n = self.num_models
+        if self._fused_args is None:
+            vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+            self._fused_args = dict(
+                forests=vp(*[device_ptr(m.forest_cu) for m, _, _ in self.m]),
+                n_trees=ci(*[int(m.num_trees) for m, _, _ in self.m]),
+                max_depth=ci(*[int(m.max_depth) for m, _, _ in self.m]),
+                n_classes=ci(*[int(m.num_classes) for m, _, _ in self.m]),
+                filter_layer=ci(*[-1 if f is None else int(f) for _, f, _ in self.m]),
+                filter_class=ci(*[-1 if c is None else int(c) for _, _, c in self.m]),
+                layer_labels=vp(*[device_ptr(b) for b in self.label_images]), vp=vp)
+        fa = self._fused_args
+        packed = None
+        if self.eval.use_packed:
+            tabs = [m.packed(scale_factor) if m.max_depth <= 27 else None for m, _, _ in self.m]
+            packed = fa["vp"](*[t.ptr if t is not None else None for t in tabs])
+        ev = self.eval
+        rc = ev._lib.rdf_layered_run(device_ptr(depth_image), int(self.depth_dims[1]), int(self.depth_dims[0]), n,
+                                     packed, fa["forests"], fa["n_trees"], fa["max_depth"], fa["n_classes"],
+                                     fa["filter_layer"], fa["filter_class"], fa["layer_labels"],
+                                     device_ptr(self.labels_images_ptrs_cu), device_ptr(self.labels_conditions_cu),
+                                     int(self.labels_conditions_cu.shape[0]), device_ptr(labels_image),
+                                     ev._composite_bad.ptr, int(self.labels_reduce), float(scale_factor),
+                                     ev._rt.stream())
+        _lib.check(ev._lib, rc, "rdf_layered_run")
+        for b in self.label_images:
+            _touch(b.cu())
+        _touch(labels_image.cu())
 
 
 class DecisionTreeEvaluator:

@@ -70,6 +70,27 @@ int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, 
                   const int32_t *cond, int n_cond, uint16_t *out, int32_t *bad_count, void *stream);
 
 /*
+ * One call for LayeredDecisionForest.run (src/decision_tree.py:233-264): every layer's forest
+ * evaluation (layer i optionally filtered on layer filter_layer[i]'s labels == filter_class[i])
+ * followed by the composite.  Equivalent to: fill composite_out and every layer_labels[i] with
+ * 65535; rdf_eval_forest[_packed] per layer in order; rdf_composite -- but the fills are fused
+ * into the kernels (they store 65535 wherever they write nothing), so a 2-layer run is 3
+ * launches instead of 6.  One image per call, as in the reference.
+ *   packed, forests, n_trees, max_depth, n_classes, filter_layer (-1 = none), filter_class,
+ *   layer_labels are HOST arrays of length n_layers (pointers inside them are device pointers;
+ *   packed may be NULL, or hold NULL entries, to evaluate from the reference-layout forest);
+ *   layer_labels_dev_table is the DEVICE pointer table the composite reads
+ *   (src/decision_tree.py:205-207).  A packed table must have been built for scale_factor.
+ */
+int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers,
+                    const void *const *packed, const float *const *forests,
+                    const int *n_trees, const int *max_depth, const int *n_classes,
+                    const int *filter_layer, const int *filter_class,
+                    uint16_t *const *layer_labels, const uint16_t *const *layer_labels_dev_table,
+                    const int32_t *cond, int n_cond, uint16_t *composite_out, int32_t *bad_count,
+                    int labels_reduce, float scale_factor, void *stream);
+
+/*
  * Load-time repack of a forest into a table of 16-byte hot records {int24 floor(s*u), int24
  * floor(s*v), integer threshold, child flags} followed by a table of 32-byte exact records
  * (fp32 s*u, s*v) that is read only for nodes whose numerators the integer form cannot

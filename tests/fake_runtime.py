@@ -57,6 +57,23 @@ class _OracleLib:
             ctypes.cast(bad, ctypes.POINTER(ctypes.c_int32))[0] += int(nb.value)
         return 0 if rc == 0 else -1
 
+    def rdf_layered_run(self, depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes,
+                        filter_layer, filter_class, layer_labels, table_dev, cond, n_cond, out, bad, r, s, stream):
+        self.calls.append(("rdf_layered_run", dim_x, dim_y, n_layers, r, float(s)))
+        lw, lh = dim_x // r, dim_y // r
+        self.rdf_fill_u16(out, lw * lh, 65535, 0)
+        for i in range(n_layers):
+            self.rdf_fill_u16(layer_labels[i], lw * lh, 65535, 0)
+        self.calls = [c for c in self.calls if c[0] != "rdf_fill_u16" or c is None]
+        for i in range(n_layers):
+            fl = filter_layer[i]
+            rc = self._o.rdf_oracle_eval_forest(depth, 1, dim_x, dim_y, forests[i], n_trees[i], max_depth[i],
+                                                n_classes[i], layer_labels[fl] if fl >= 0 else None,
+                                                filter_class[i] if fl >= 0 else -1, layer_labels[i], r, s, None, 0)
+            if rc != 0:
+                return -1
+        return self.rdf_composite(table_dev, n_layers, lw, lh, cond, n_cond, out, bad, stream)
+
     def rdf_fill_u16(self, dst, n, value, stream):
         self.calls.append(("rdf_fill_u16", int(n), int(value)))
         arr = (ctypes.c_uint16 * int(n)).from_address(int(dst))

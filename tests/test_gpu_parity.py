@@ -117,7 +117,9 @@ def test_layered_run_on_gpu_matches_golden(rdf, gpu_runtime, tmp_path):
     lf = rdf.LayeredDecisionForest.load(str(tmp_path / "cfg.json"), (60, 84), labels_reduce=2)
     depth, labels = rdf.GpuBuffer((60, 84), np.uint16), rdf.GpuBuffer((30, 42), np.uint16)
     depth.cu().set(g["g3_depth"][0])
-    for _ in range(2):  # second run: buffers are re-filled, result identical
+    for fused in (True, False, True):  # one-call path, reference-like sequence, and again (buffers re-filled)
+        lf.fused = fused
+        labels.cu().fill(12345)
         lf.run(depth, labels, 1.0)
         assert np.array_equal(lf.label_images[0].cu().get(), g["g3_l0"][0])
         assert np.array_equal(lf.label_images[1].cu().get(), g["g3_l1"][0])

@@ -134,6 +134,7 @@ def test_layered_forest_run_matches_golden(rdf, host_runtime, tmp_path):
     g = np.load(GOLDEN)
     cfg = _write_layered_cfg(tmp_path, g)
     lf = rdf.LayeredDecisionForest.load(cfg, (60, 84), labels_reduce=2)
+    lf.fused = False   # the reference's step-by-step sequence; the one-call path is tested below
     assert lf.labels_dims == (30, 42) and lf.num_models == 2 and lf.num_layered_classes == 4
     assert lf.label_colors.shape == (4, 4) and len(lf.label_images) == 2
     depth = rdf.GpuBuffer((60, 84), np.uint16)
@@ -150,6 +151,20 @@ def test_layered_forest_run_matches_golden(rdf, host_runtime, tmp_path):
     assert names[-6:] == ["rdf_fill_u16"] * 3 + ["rdf_eval_forest_packed"] * 2 + ["rdf_composite"]
     evals = [c for c in host_runtime.lib.calls if c[0] == "rdf_eval_forest_packed"]
     assert evals[-2][7] == -1 and evals[-1][7] == 3 and evals[-1][8] == 2
+
+
+def test_layered_forest_fused_run_equals_stepwise(rdf, host_runtime, tmp_path):
+    g = np.load(GOLDEN)
+    lf = rdf.LayeredDecisionForest.load(_write_layered_cfg(tmp_path, g), (60, 84), labels_reduce=2)
+    assert lf.fused
+    depth, labels = rdf.GpuBuffer((60, 84), np.uint16), rdf.GpuBuffer((30, 42), np.uint16)
+    depth.cu().set(g["g3_depth"][0])
+    labels.cu().fill(7)
+    lf.run(depth, labels, 1.0)
+    assert [c[0] for c in host_runtime.lib.calls if c[0].startswith("rdf_layered")] == ["rdf_layered_run"]
+    assert np.array_equal(lf.label_images[0].cu().get(), g["g3_l0"][0])
+    assert np.array_equal(lf.label_images[1].cu().get(), g["g3_l1"][0])
+    assert np.array_equal(labels.cu().get(), g["g3_comp"][0])
 
 
 def test_layered_cfg_validation(rdf, host_runtime, tmp_path):
