@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--topology", default="full")
     ap.add_argument("--unpacked", action="store_true")
     ap.add_argument("--kinds", default="mixed", choices=["mixed", "interleaved", "dense", "live"])
+    ap.add_argument("--reduce", type=int, default=1)
     ap.add_argument("combos", nargs="*", default=["1024:81920", "512:81920", "512:32768", "256:32768", "256:16384"])
     a = ap.parse_args()
     import torch
@@ -34,7 +35,8 @@ def main():
              "dense": ["dense"] * a.frames, "live": ["live"] * a.frames}[a.kinds]
     host = rdf.synth.mixed_batch(a.frames) if kinds is None else rdf.synth.frames(kinds)
     depth = rdf.to_device(host)
-    labels = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
+    red = a.reduce
+    labels = rdf.DeviceArray((host.shape[0], host.shape[1] // red, host.shape[2] // red), np.uint16).fill(65535)
     ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
     combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]   # block:lds[:rows_per_wave[:halo]]
     res = {c: [] for c in combos}
@@ -48,7 +50,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(a.reps):
-                ev.get_labels_forest(forest, depth, labels)
+                ev.get_labels_forest(forest, depth, labels, red)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.reps
             if r:
