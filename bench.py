@@ -295,6 +295,15 @@ def main():
                                              f"{t_cpu:.1f} s of oracle/rdf_oracle.c (OpenMP, -O2) on the host; "
                                              f"GPU labels of those frames differ in {mism} pixels"}
             assert mism == 0, f"GPU labels differ from the oracle in {mism} pixels"
+            # what a "numpy fallback" would have been (variant ii): level-synchronous numpy, one process
+            from oracle import rdf_numpy
+            wn = np.full((1, H, W), 65535, np.uint16)
+            tn = time.perf_counter()
+            rdf_numpy.eval_forest(frames_np[F - 1:F], forest_np, wn)
+            tn = time.perf_counter() - tn
+            out["cpu_baseline_numpy"] = {"value": round(H * W / tn / 1e6, 3), "unit": "Mpix/s", "cores": 1,
+                                         "kind": "port", "sample": f"1 live-like frame, {tn:.1f} s of oracle/rdf_numpy.py; "
+                                         f"labels differ from the GPU's in {int((wn[0] != got[F - 1]).sum())} pixels"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -308,3 +308,33 @@ def test_config5_shape_bit_exact(rdf, evs, oracle):
     got = _gpu_forest(rdf, evs["packed"], depth, forest, 65535)
     assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ"
     del forest
+
+
+def test_hipgraph_capture_and_replay(rdf, evs, oracle, gpu_runtime):
+    """The forest launch (dynamic tile queue with a self-resetting slot) can be captured into a hipGraph and
+    replayed: same labels on every replay, also after the input frame changes in place."""
+    import torch
+    synth = rdf.synth
+    forest_np = synth.forest(4, 10, 4, "trained")
+    forest = rdf.DecisionForest.from_numpy(forest_np)
+    frames = synth.frames(["live", "dense"], 60, 120, 160)
+    depth = rdf.to_device(frames[0:1])
+    labels = rdf.DeviceArray((1, 120, 160), np.uint16)
+    ev = evs["packed"]
+    forest.packed(1.0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):          # warm-up on the capture stream (occupancy query, queue slot)
+        labels.fill(65535)
+        ev.get_labels_forest(forest, depth, labels)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        labels.fill(65535)
+        ev.get_labels_forest(forest, depth, labels)
+    for i in (0, 1, 0):
+        depth.set(frames[i:i + 1])
+        graph.replay()
+        torch.cuda.synchronize()
+        want = np.full((1, 120, 160), 65535, np.uint16)
+        oracle.eval_forest(frames[i:i + 1], forest_np, want)
+        assert np.array_equal(labels.get(), want), f"replay on frame {i}"
