@@ -5,6 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rdf_hip.hip")
+SOURCES = [SRC, os.path.join(HERE, "csrc", "mean_shift_hip.hip"), os.path.join(HERE, "csrc", "points_ops_hip.hip")]
 HDR = os.path.join(HERE, "..", "include", "rdf_hip.h")
 SO = os.path.join(HERE, "csrc", "librdf_hip.so")
 
@@ -22,14 +23,14 @@ def is_stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in (SRC, HDR, __file__))
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + [HDR, __file__])
 
 
 def build(force=False, verbose=False):
     """Compile the HIP extension in-tree.  Returns the path of the shared library."""
     if not force and not is_stale():
         return SO
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", SO + ".tmp", SRC]
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", SO + ".tmp"] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -27,6 +27,15 @@ SIGNATURES = {
                                         _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "rdf_eval_forest_stats": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                                        _c_void_p, _c_int, _c_void_p, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "rdf_mean_shift_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "rdf_mean_shift": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_fingertip_heights": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
+                                       _c_float, _c_float, _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_convert_0s_to_maxuint": (_c_int, [_c_void_p, _c_size_t, _c_void_p]),
+    "rdf_setup_depth_image_for_forest": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "rdf_stencil_depth_image_by_group": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_flip_x": (_c_int, [_c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_make_rgba_from_labels": (_c_int, [_c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_fill_u16": (_c_int, [_c_void_p, _c_size_t, ctypes.c_uint16, _c_void_p]),
     "rdf_debug_floor_i32": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_debug_div_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

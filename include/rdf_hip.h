@@ -121,6 +121,53 @@ int rdf_eval_forest_stats(const uint16_t *depth, int n_img, int dim_x, int dim_y
                           uint16_t *labels_out, int labels_reduce, float scale_factor,
                           unsigned long long *stats, void *stream);
 
+/*
+ * ---- consumer of the composite label map ----
+ * Per-class 2-D mean-shift mode finding.  Replaces the kernel `run` of src/cuda/mean_shift.cu:3-48
+ * AND the host loop of src/cuda/mean_shift.py:35-59 (per round: zero the sums, launch, copy sums and
+ * means to the host, divide, add, copy back): all `num_rounds` rounds run on the device, one launch
+ * per round, no host round trip, bitwise-reproducible sums (no atomics).
+ *   labels     uint16 [dim_y][dim_x]; 0, 65535 and values > num_classes are ignored
+ *   variances  float32 [num_classes] (device)
+ *   means_out  float64 [num_classes][2] = (x, y) per class (device); NaN for a class without pixels,
+ *              as the reference's 0/0
+ *   workspace  rdf_mean_shift_workspace_bytes() bytes of device memory (contents irrelevant)
+ * num_classes <= 64.
+ */
+size_t rdf_mean_shift_workspace_bytes(int num_classes, int num_rounds);
+int rdf_mean_shift(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,
+                   int num_rounds, double *means_out, void *workspace, void *stream);
+
+/*
+ * Height of each requested class's mode above the calibrated plane.  Replaces the host code of
+ * src/3d_bz.py:503-522: px,py = int(mean) * labels_reduce; z = depth[py][px];
+ * pt = rs2_deproject_pixel_to_point (librealsense2, distortion-free intrinsics: z*((px-ppx)/fx,
+ * (py-ppy)/fy, 1) in fp32); height = -(plane @ [pt,1]).z.  NaN where the reference "resets" the
+ * fingertip (mode off-frame or NaN).
+ *   means float64 [num_classes][2] (device); class_ids int32 [n_ids] (device, 1-based labels);
+ *   plane float32 [4][4] row-major (device); heights_out float64 [n_ids] (device)
+ */
+int rdf_fingertip_heights(const double *means, int num_classes, const int *class_ids, int n_ids,
+                          const uint16_t *depth, int dim_x, int dim_y, int labels_reduce, float fx, float fy,
+                          float ppx, float ppy, const float *plane, double *heights_out, void *stream);
+
+/*
+ * ---- element-wise kernels either side of the forest; all in place / byte exact ----
+ * rdf_convert_0s_to_maxuint           src/cuda/points_ops.cu:117-127   depth[i] == 0 -> 65535
+ * rdf_setup_depth_image_for_forest    :149-165   depth[i] == 0 or pts[i].w == 0 -> 65535 (pts = float4 per pixel)
+ * rdf_stencil_depth_image_by_group    :440-463   d_out[y][x] = d_in[y][x] where groups[y>>level][x>>level] == group
+ * rdf_flip_x                          :466-483   out[y][W-1-x] = in[y][x]
+ * rdf_make_rgba_from_labels           :258-281   image[y][x] = colors[l-1] for labels l not in {0, 65535};
+ *                                                labels > num_colors are skipped (the reference reads from nullptr)
+ */
+int rdf_convert_0s_to_maxuint(uint16_t *depth, size_t num_pixels, void *stream);
+int rdf_setup_depth_image_for_forest(const float *pts_xyzw, uint16_t *depth, size_t num_pixels, void *stream);
+int rdf_stencil_depth_image_by_group(int dim_x, int dim_y, int mipmap_level, int group, const uint16_t *groups_in,
+                                     const uint16_t *depth_in, uint16_t *depth_out, void *stream);
+int rdf_flip_x(int dim_x, int dim_y, const uint16_t *in, uint16_t *out, void *stream);
+int rdf_make_rgba_from_labels(int dim_x, int dim_y, int num_colors, const uint16_t *labels,
+                              const uint8_t *colors_rgba, uint8_t *image_rgba, void *stream);
+
 /* GPUArray.fill(65535) of src/decision_tree.py:237-240 for uint16 buffers. */
 int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
 

@@ -1,0 +1,83 @@
+"""mean-shift modes of the composite label map + fingertip heights.
+CPU: the numpy restatement against hand-derived answers.  GPU (-m gpu): rdf_mean_shift /
+rdf_fingertip_heights against the restatement within 1e-9 (the reference's own fp64 atomics are
+order-dependent, so this row has no bit-exact target), plus run-to-run bitwise reproducibility."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import mean_shift_numpy as ms_np
+
+
+def _label_map(seed=3, h=120, w=212, n_classes=6, absent=(5,)):
+    rng = np.random.default_rng(seed)
+    lab = np.full((h, w), 65535, dtype=np.uint16)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for c in range(1, n_classes + 1):
+        if c in absent:
+            continue
+        cx, cy = rng.uniform(20, w - 20), rng.uniform(15, h - 15)
+        a, b = rng.uniform(4, 14), rng.uniform(4, 14)
+        m = ((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1
+        lab[m] = c
+        for _ in range(3):   # outliers that the kernel weighting should discount
+            lab[rng.integers(0, h), rng.integers(0, w)] = c
+    lab[0, 0] = 0
+    lab[1, 1] = 60000        # label beyond num_classes: ignored here (the reference would fault)
+    return lab
+
+
+def test_known_answers_numpy():
+    # one pixel per class: round 0 puts the mean on it, later rounds shift by exactly 0 (diff = 0, weight 1)
+    lab = np.zeros((5, 7), np.uint16)
+    lab[2, 3], lab[4, 6] = 1, 2
+    m = ms_np.mean_shift(lab, 3, [1.0, 2.0, 3.0], 6)
+    assert m[0].tolist() == [3.0, 2.0] and m[1].tolist() == [6.0, 4.0] and np.isnan(m[2]).all()
+    # two pixels of a class, symmetric: the centroid is a fixed point (shifts cancel exactly)
+    lab = np.zeros((1, 9), np.uint16)
+    lab[0, 2] = lab[0, 6] = 1
+    m = ms_np.mean_shift(lab, 1, [2.0], 4)
+    assert m[0].tolist() == [4.0, 0.0]
+    # zero rounds: the zero-initialised means come back (mean_shift.py:33)
+    assert (ms_np.mean_shift(lab, 1, [2.0], 0) == 0).all()
+    # height: identity plane => -z ; mean (10.9, 5.2) truncates to pixel (10, 5), times labels_reduce 2
+    depth = np.arange(40 * 60, dtype=np.uint16).reshape(40, 60)
+    hts = ms_np.fingertip_heights(np.array([[10.9, 5.2], [np.nan, 1.0], [100.0, 3.0]]), [1, 2, 3], depth, 2,
+                                  400.0, 400.0, 30.0, 20.0, np.eye(4, dtype=np.float32))
+    assert hts[0] == -float(depth[10, 20]) and np.isnan(hts[1]) and np.isnan(hts[2])
+
+
+@pytest.mark.gpu
+def test_mean_shift_matches_restatement_and_is_reproducible(rdf, gpu_runtime):
+    msmod = importlib.import_module("3d-beats_amd.cuda.mean_shift")
+    ms = msmod.MeanShift()
+    for seed, (h, w), L in [(3, (120, 212), 6), (4, (240, 424), 7), (5, (33, 65), 2), (6, (480, 848), 6)]:
+        lab = _label_map(seed, h, w, L, absent=(min(5, L),))
+        var = np.linspace(6.0, 14.0, L).astype(np.float32)
+        dl, dv = rdf.to_device(lab[None]), rdf.to_device(var)
+        for rounds in (0, 1, 6):
+            got = ms.run(rounds, dl, L, dv)
+            want = ms_np.mean_shift(lab, L, var, rounds)
+            assert got.shape == (L, 2) and got.dtype == np.float64
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            ok = ~np.isnan(want)
+            assert np.abs(got[ok] - want[ok]).max() < 1e-9, (seed, rounds, np.abs(got[ok] - want[ok]).max())
+            again = ms.run(rounds, dl, L, dv)
+            assert np.array_equal(got.view(np.uint64), again.view(np.uint64)), "not bitwise reproducible"
+
+
+@pytest.mark.gpu
+def test_fingertip_heights_match_restatement(rdf, gpu_runtime):
+    msmod = importlib.import_module("3d-beats_amd.cuda.mean_shift")
+    rng = np.random.default_rng(9)
+    depth = rdf.synth.frames(["dense"], 77, 480, 848)[0]
+    means = np.array([[100.7, 50.2], [423.9, 239.9], [424.0, 10.0], [-0.5, 3.0], [np.nan, 1.0], [12.0, 240.0], [0.0, 0.0]])
+    plane = (np.eye(4) + 0.1 * rng.standard_normal((4, 4))).astype(np.float32)
+    ids = [1, 2, 3, 4, 5, 6, 7]
+    got = msmod.fingertip_heights(rdf.to_device(means), ids, rdf.to_device(depth), 2, 421.3, 420.9, 423.1, 238.6, plane)
+    want = ms_np.fingertip_heights(means, ids, depth, 2, 421.3, 420.9, 423.1, 238.6, plane)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (got, want)
+    ok = ~np.isnan(want)
+    assert np.allclose(got[ok], want[ok], rtol=1e-6, atol=1e-6), (got, want)
+    assert np.isnan(want[[2, 4, 5]]).all() and not np.isnan(want[[0, 1, 3, 6]]).any()
