@@ -1,0 +1,139 @@
+"""On-disk dataset directories of 3d-beats, read side only.
+
+Layout written by the reference's data generators (src/live_data_convert.py:287-298, 456-458) and read by
+`DecisionTreeDatasetConfig` (src/decision_tree.py:21-122):
+
+    <dir>/config.json            {"img_dims": [W, H], "num_images": N, "id_to_color": {"0": [0,0,0,0], "1": [r,g,b,255], ...}}
+    <dir>/00000000_depth.png     16-bit depth, background already 65535
+    <dir>/00000000_labels.png    16-bit class ids (0 = unlabelled)
+
+This class keeps the reference's constructor, attributes and block getters so that harnesses such as
+src/test_on_saved_model.py:44-56 run unchanged, but blocks are plain device arrays filled from the PNGs
+(the reference stages them through nvcomp-compressed blocks, which is training-side machinery).
+"""
+import json
+import os
+
+import numpy as np
+
+
+class DecisionTreeDatasetConfig:
+    def __init__(self, dataset_dir, num_images=0, images_per_block=0, imgs_name='data0', shuffle=True):
+        self.dataset_dir = dataset_dir
+        with open(os.path.join(dataset_dir, 'config.json')) as fh:
+            cfg = json.loads(fh.read())
+        self.cfg = cfg
+        self.imgs_name = imgs_name
+
+        self.img_dims = tuple(cfg['img_dims'])  # (x, y)
+        self.id_to_color = {0: np.array([0, 0, 0, 0], dtype=np.uint8)}
+        for i, c in cfg['id_to_color'].items():
+            self.id_to_color[int(i)] = np.array(c, dtype=np.uint8)
+
+        self.total_available_images = cfg['num_images']
+        self.num_images = num_images
+        if self.num_images == 0:
+            return
+        assert self.num_images <= self.total_available_images
+
+        self.images_per_block = images_per_block or self.num_images
+        assert self.num_images % self.images_per_block == 0
+        self.num_image_blocks = self.num_images // self.images_per_block
+
+        idxes = list(range(self.total_available_images))
+        if shuffle:
+            np.random.shuffle(idxes)   # the reference draws from the global numpy RNG (decision_tree.py:68)
+        self.img_idxes = idxes[0:self.num_images]
+
+    # -- reading -----------------------------------------------------------------------------
+    def _load(self, img_idx, name):
+        from PIL import Image
+        path = os.path.join(self.dataset_dir, f'{str(img_idx).zfill(8)}_{name}.png')
+        a = np.array(Image.open(path)).astype(np.uint16)
+        assert a.shape == (self.img_dims[1], self.img_dims[0]), f'{path}: {a.shape}'
+        return a
+
+    def get_block_cpu(self, block_num, name):
+        out = np.empty((self.images_per_block, self.img_dims[1], self.img_dims[0]), dtype=np.uint16)
+        for j in range(self.images_per_block):
+            out[j] = self._load(self.img_idxes[block_num * self.images_per_block + j], name)
+        return out
+
+    def get_depth_block_cu(self, block_num, arr_out):
+        arr_out.set(self.get_block_cpu(block_num, 'depth'))
+
+    def get_labels_block_cu(self, block_num, arr_out):
+        arr_out.set(self.get_block_cpu(block_num, 'labels'))
+
+    # -- bookkeeping (decision_tree.py:85-122) -------------------------------------------------
+    def num_classes(self):
+        return len(self.id_to_color)
+
+    def num_pixels(self):
+        return self.num_images * self.img_dims[0] * self.img_dims[1]
+
+    def images_shape(self):
+        return (self.num_images, self.img_dims[1], self.img_dims[0])
+
+    def convert_colors_to_ids(self, labels_color):
+        ids = np.zeros((self.img_dims[1], self.img_dims[0]), dtype=np.uint16)
+        seen = 0
+        for class_id, color in self.id_to_color.items():
+            m = np.all(labels_color == color, axis=2)
+            ids[m] = class_id
+            seen += int(m.sum())
+        assert seen == self.img_dims[0] * self.img_dims[1], 'every pixel must carry a known label colour'
+        return ids
+
+    def convert_ids_to_colors(self, labels_ids):
+        n, y, x = labels_ids.shape
+        assert (y, x) == (self.img_dims[1], self.img_dims[0])
+        out = np.zeros((n, y, x, 4), dtype=np.uint8)
+        for class_id, color in self.id_to_color.items():
+            out[labels_ids == class_id] = color
+        return out
+
+
+def write_dataset(dataset_dir, depth, labels, id_to_color):
+    """Writes a dataset directory in the layout above (used by tests and tools; the reference's writer is
+    its GL data generator).  depth, labels: uint16 [N, H, W]; id_to_color: {id: [r, g, b, a]} without id 0."""
+    from PIL import Image
+    os.makedirs(dataset_dir, exist_ok=True)
+    n, h, w = depth.shape
+    cfg = {'img_dims': [int(w), int(h)], 'num_images': int(n), 'id_to_color': {'0': [0, 0, 0, 0]}}
+    for k, c in id_to_color.items():
+        cfg['id_to_color'][str(int(k))] = [int(v) for v in c]
+    with open(os.path.join(dataset_dir, 'config.json'), 'w') as fh:
+        fh.write(json.dumps(cfg))
+    for i in range(n):
+        Image.fromarray(np.ascontiguousarray(depth[i], dtype=np.uint16)).save(
+            os.path.join(dataset_dir, f'{str(i).zfill(8)}_depth.png'))
+        Image.fromarray(np.ascontiguousarray(labels[i], dtype=np.uint16)).save(
+            os.path.join(dataset_dir, f'{str(i).zfill(8)}_labels.png'))
+
+
+def evaluate_saved_model(model_path, dataset_dir, num_images, out_dir=None):
+    """The accuracy harness of src/test_on_saved_model.py:23-67 without the GLFW window: returns
+    `pct. matching pixels` = matches / labelled pixels, optionally saving colour renders."""
+    from .decision_tree import DecisionForest, DecisionTreeEvaluator
+    from .device import DeviceArray
+    from .util import MAX_UINT16
+    forest = DecisionForest.load(model_path)
+    ev = DecisionTreeEvaluator()
+    ds = DecisionTreeDatasetConfig(dataset_dir, num_images=num_images, imgs_name='test')
+    depth = DeviceArray(ds.images_shape(), np.uint16)
+    ds.get_depth_block_cu(0, depth)
+    truth = DeviceArray(ds.images_shape(), np.uint16)
+    ds.get_labels_block_cu(0, truth)
+    truth_cpu = truth.get()
+    out = DeviceArray(ds.images_shape(), np.uint16).fill(MAX_UINT16)
+    ev.get_labels_forest(forest, depth, out)
+    got = out.get()
+    pct = float(np.sum(got == truth_cpu) / np.sum(truth_cpu > 0))
+    if out_dir:
+        from PIL import Image
+        os.makedirs(out_dir, exist_ok=True)
+        render = ds.convert_ids_to_colors(got)
+        for i in range(ds.num_images):
+            Image.fromarray(render[i]).save(os.path.join(out_dir, f'eval_labels_{str(i).zfill(8)}.png'))
+    return pct
