@@ -338,3 +338,70 @@ def test_hipgraph_capture_and_replay(rdf, evs, oracle, gpu_runtime):
         want = np.full((1, 120, 160), 65535, np.uint16)
         oracle.eval_forest(frames[i:i + 1], forest_np, want)
         assert np.array_equal(labels.get(), want), f"replay on frame {i}"
+
+
+def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
+    """Seeded fuzz: 60 random (shape, forest, reduce, scale, filter, pre-fill, launch-geometry) combinations,
+    each bit-exact against the C oracle on both paths."""
+    rng = np.random.default_rng(20211003)
+    lib = gpu_runtime.lib
+    try:
+        for it in range(60):
+            T, D, C = int(rng.integers(1, 10)), int(rng.integers(1, 12)), int(rng.integers(1, 20))
+            n, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 90)), int(rng.integers(1, 200))
+            r = int(rng.choice([1, 1, 2, 3, 7]))
+            s = float(rng.choice([1.0, 0.5, 0.25, 1.5, 2.0]))
+            forest = rdf.synth.forest(T, D, C, str(rng.choice(["full", "trained"])), first_tree=it)
+            if rng.random() < 0.3:      # a few wild nodes: huge / tiny / non-finite numerators and thresholds
+                k = (forest.shape[1] + 1) // 2
+                forest[:, :k, 0:5] *= rng.choice([1e-30, 1e30, 1e6, np.nan, np.inf], size=(T, k, 5)).astype(np.float32) \
+                    * (rng.random((T, k, 5)) < 0.2) + (rng.random((T, k, 5)) >= 0.2)
+            kinds = [str(k) for k in rng.choice(["dense", "live"], size=n)]
+            depth = rdf.synth.frames(kinds, 3000 + it, h, w)
+            depth[rng.random(depth.shape) < 0.02] = 0
+            use_filter = rng.random() < 0.4
+            filt = rng.integers(0, 3, size=(n, h // r, w // r)).astype(np.uint16) if use_filter else None
+            prefill = int(rng.choice([65535, 0, 31337]))
+            lib.rdf_set_block_threads(int(rng.choice([0, 256, 512, 1024])))
+            lib.rdf_set_halo(int(rng.choice([-1, 0, 5, 16, 33])))
+            lib.rdf_set_rows_per_wave(int(rng.choice([0, 1, 2, 4])))
+            lib.rdf_set_scheduler(int(rng.choice([-1, 0, 1])))
+            lib.rdf_set_lds_budget_bytes(int(rng.choice([0, 1, 9000, 40000, 120000])))
+            want = np.full((n, h // r, w // r), prefill, np.uint16)
+            oracle.eval_forest(depth, forest, want, r, filt, 2 if use_filter else None, s)
+            for path in ("packed", "direct"):
+                got = _gpu_forest(rdf, evs[path], depth, forest, prefill, r, filt, 2 if use_filter else None, s)
+                assert np.array_equal(got, want), f"iteration {it} ({path}): T{T} D{D} C{C} {n}x{h}x{w} r{r} s{s}"
+    finally:
+        lib.rdf_set_block_threads(0)
+        lib.rdf_set_halo(-1)
+        lib.rdf_set_rows_per_wave(0)
+        lib.rdf_set_scheduler(-1)
+        lib.rdf_set_lds_budget_bytes(0)
+
+
+def test_two_streams_do_not_share_queue_state(rdf, evs, oracle, gpu_runtime):
+    """Launches on two streams run concurrently with their own tile-queue slots."""
+    import torch
+    synth = rdf.synth
+    fa, fb = synth.forest(4, 12, 4, "trained", 1), synth.forest(3, 11, 5, "full", 9)
+    da, db = synth.frames(["dense"] * 6, 800, 240, 424), synth.frames(["live"] * 6, 900, 200, 300)
+    wa, wb = np.full(da.shape, 65535, np.uint16), np.full(db.shape, 65535, np.uint16)
+    oracle.eval_forest(da, fa, wa)
+    oracle.eval_forest(db, fb, wb)
+    Fa, Fb = rdf.DecisionForest.from_numpy(fa), rdf.DecisionForest.from_numpy(fb)
+    Da, Db = rdf.to_device(da), rdf.to_device(db)
+    La, Lb = rdf.DeviceArray(da.shape, np.uint16), rdf.DeviceArray(db.shape, np.uint16)
+    Fa.packed(1.0), Fb.packed(1.0)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = evs["packed"]
+    for _ in range(5):
+        with torch.cuda.stream(sa):
+            La.fill(65535)
+            ev.get_labels_forest(Fa, Da, La)
+        with torch.cuda.stream(sb):
+            Lb.fill(65535)
+            ev.get_labels_forest(Fb, Db, Lb)
+    torch.cuda.synchronize()
+    assert np.array_equal(La.get(), wa) and np.array_equal(Lb.get(), wb)
