@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="eval/gather pipeline chunks per step (0: 1 at N=1, 8 at N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed batch (no cfg2/cfg3/PCIe/CPU legs): "
+                    "what tools/profile.sh traces so that rocprofv3's per-kernel average is the headline kernel's")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
                     "rehearse the control flow with several ranks on one GPU)")
@@ -216,7 +218,7 @@ def main():
                      "visits": {"pixels": int(stats[0]), "node_records": int(stats[1]), "leaves": int(stats[2])}},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.headline_only:
         # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
         one_d, one_l = depth[0:1], rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
         for _ in range(10):

@@ -7,14 +7,14 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 5 --headline-only \
     > $O/bench_traced.json 2> $O/trace.err
 cp $O/trace/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 for spec in fetch:"FETCH_SIZE TCC_HIT_sum" write:"WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" grbm:"GRBM_GUI_ACTIVE" \
             tcp:"TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
             sq:"SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   name=${spec%%:*}; ctrs=${spec#*:}
-  timeout -k 5 150 rocprofv3 --pmc $ctrs --output-format csv -d $O/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline \
+  timeout -k 5 150 rocprofv3 --pmc $ctrs --output-format csv -d $O/$name -- python3 $R/bench.py --steps 3 --warmup 1 --headline-only \
       > $O/$name.json 2> $O/$name.err
   echo "pass $name rc=$?"
 done
