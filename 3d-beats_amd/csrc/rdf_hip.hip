@@ -58,7 +58,7 @@ __device__ unsigned int g_sched[kSchedSlots][2];
 // Hot record, 16 bytes, one 128-bit load per node:
 //   w0 = int24 floor(s*u.x) | T[7:0]   << 24        T = integer threshold (see thresh_to_int)
 //   w1 = int24 floor(s*u.y) | T[15:8]  << 24
-//   w2 = int24 floor(s*v.x) | T[17:16] << 24
+//   w2 = int24 floor(s*v.x) | (T >> 16) << 24       (signed byte: -1, 0 or 1)
 //   w3 = int24 floor(s*v.y) | flags    << 24        flags: kFlagLeft/Right = that child continues,
 //                                                          kFlagExact = use the exact record
 // Why integers are enough: for every depth d in [1,65534] and every fp32 a that is +-0 or has a
@@ -162,11 +162,11 @@ __device__ __forceinline__ NodeRec16 encode_node(float sux, float suy, float svx
     } else {
         flags |= kFlagExact;
     }
-    const uint32_t t = (uint32_t)thresh_to_int(thresh) & 0x3FFFFu;
+    const uint32_t t = (uint32_t)thresh_to_int(thresh);   // two's complement, |T| <= 65536
     NodeRec16 r;
     r.w[0] = ((uint32_t)nx & 0xFFFFFFu) | ((t & 0xFFu) << 24);
     r.w[1] = ((uint32_t)ny & 0xFFFFFFu) | (((t >> 8) & 0xFFu) << 24);
-    r.w[2] = ((uint32_t)mx & 0xFFFFFFu) | (((t >> 16) & 0x3u) << 24);
+    r.w[2] = ((uint32_t)mx & 0xFFFFFFu) | (((t >> 16) & 0xFFu) << 24);
     r.w[3] = ((uint32_t)my & 0xFFFFFFu) | (flags << 24);
     return r;
 }
@@ -189,8 +189,10 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
     n.ay = (float)((int)(w.y << 8) >> 8);
     n.bx = (float)((int)(w.z << 8) >> 8);
     n.by = (float)((int)(w.w << 8) >> 8);
-    const uint32_t t = (w.x >> 24) | ((w.y >> 24) << 8) | ((w.z >> 24) << 16);
-    n.t = (int)(t << 14) >> 14;
+    // T = {w0.b3, w1.b3, w2.b3, sign(w2.b3)} in two byte permutes (v_perm_b32: selectors 0-3 pick bytes of the
+    // second operand, 4-7 of the first, 11 replicates the sign of the first operand's top byte, 12 is 0x00)
+    const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0703u);
+    n.t = (int)__builtin_amdgcn_perm(w.z, lo, 0x0b070100u);
     n.flags = w.w >> 24;
     return n;
 }
@@ -213,18 +215,23 @@ struct Probe {
     bool in_tile, inb;
 };
 
-__device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int x, int y)
+// (cx, cy) = probe position RELATIVE TO THE STAGED TILE (the caller adds the offsets to the pixel's own
+// tile-relative position); image coordinates are only rebuilt for lanes that leave the tile.
+__device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int cx, int cy)
 {
     Probe p;
-    const uint32_t cx = (uint32_t)(x - c.tx0), cy = (uint32_t)(y - c.ty0);
-    p.in_tile = cx < (uint32_t)c.tw && cy < (uint32_t)c.th;
-    p.inb = (uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H;
-    const uint32_t li = p.in_tile ? __umul24(cy, (uint32_t)c.twp) + cx : 0u;
+    p.in_tile = (uint32_t)cx < (uint32_t)c.tw && (uint32_t)cy < (uint32_t)c.th;
+    const uint32_t li = p.in_tile ? __umul24((uint32_t)cy, (uint32_t)c.twp) + (uint32_t)cx : 0u;
     p.lds_v = c.tile[li];
     p.glb_v = 0u;
-    if (p.inb && !p.in_tile) {   // only far lanes touch global memory; the value is consumed after the branch
-        const uint32_t go = (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1;
-        p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
+    p.inb = false;
+    if (!p.in_tile) {
+        const int x = add_wrap(cx, c.tx0), y = add_wrap(cy, c.ty0);
+        p.inb = (uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H;
+        if (p.inb) {   // only far lanes touch global memory; the value is consumed after the branch
+            const uint32_t go = (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1;
+            p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
+        }
     }
     return p;
 }
@@ -350,7 +357,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             bool skip = false;
             if (a.filter_class != -1) skip = (int)a.filter[i] != a.filter_class;
             uint32_t d = 0u;
-            if (!skip) d = (uint32_t)probe_value(probe_issue(pc, x, y));
+            const int xl = x - tx0, yl = y - ty0;   // this pixel, relative to the staged tile
+            if (!skip) d = (uint32_t)probe_value(probe_issue(pc, xl, yl));
             if (skip || d == 0u || d == kNoPixel) {
                 if (a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
                 continue;
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             }
                         }
 
-                        // ---- probe coordinates: x + floor((s*u.x)/d) ... (decision_tree_common.hpp:15-22) ----
+                        // ---- probe coordinates x + floor((s*u.x)/d) ... (decision_tree_common.hpp:15-22), kept relative to the tile ----
                         int ux[kGroup], uy[kGroup], vx[kGroup], vy[kGroup];
                         uint32_t fl = 0u;
 #pragma unroll
@@ -443,10 +451,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             }
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
-                                ux[k] = add_wrap(x, floor_i32(n[k].ax / df));
-                                uy[k] = add_wrap(y, floor_i32(n[k].ay / df));
-                                vx[k] = add_wrap(x, floor_i32(n[k].bx / df));
-                                vy[k] = add_wrap(y, floor_i32(n[k].by / df));
+                                ux[k] = add_wrap(xl, floor_i32(n[k].ax / df));
+                                uy[k] = add_wrap(yl, floor_i32(n[k].ay / df));
+                                vx[k] = add_wrap(xl, floor_i32(n[k].bx / df));
+                                vy[k] = add_wrap(yl, floor_i32(n[k].by / df));
                             }
                         } else {
                             // q0 = a*rcp; rem = a - d*q0 (exact, fma); q = q0 + rem*rcp.  Packed f32 math,
@@ -461,10 +469,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                                 const f2 rv = __builtin_elementwise_fma(ndf2, qv0, nv);
                                 const f2 qu = __builtin_elementwise_fma(ru, rcp2, qu0);
                                 const f2 qv = __builtin_elementwise_fma(rv, rcp2, qv0);
-                                ux[k] = add_wrap(x, floor_i32_not_nan(qu.x));
-                                uy[k] = add_wrap(y, floor_i32_not_nan(qu.y));
-                                vx[k] = add_wrap(x, floor_i32_not_nan(qv.x));
-                                vy[k] = add_wrap(y, floor_i32_not_nan(qv.y));
+                                ux[k] = add_wrap(xl, floor_i32_not_nan(qu.x));
+                                uy[k] = add_wrap(yl, floor_i32_not_nan(qu.y));
+                                vx[k] = add_wrap(xl, floor_i32_not_nan(qv.x));
+                                vy[k] = add_wrap(yl, floor_i32_not_nan(qv.y));
                             }
                         }
 
