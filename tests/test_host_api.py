@@ -199,3 +199,28 @@ def test_batches_beyond_2_31_pixels_are_chunked(rdf):
     assert all(n * 848 * 480 < 2 ** 31 for _, n in chunks)
     assert chunks[0][0] == 0 and chunks[1][0] == chunks[0][1]
     assert dt._image_chunks(1, 848 * 480) == [(0, 1)]
+
+
+def test_config1_single_frame_plumbing_on_cpu(rdf, host_runtime, oracle, oracle_np):
+    """BASELINE config 1: one live-like 848x480 frame, 1 tree of depth 10, no GPU -- the reference-shaped API
+    end to end on the host-memory test double (the product itself has no CPU backend), C and numpy
+    restatements agreeing on the full-size frame."""
+    synth = rdf.synth
+    forest_np = synth.forest(1, 10, 4, "full")
+    frame = synth.frames(["live"], 0)
+    forest = rdf.DecisionForest.from_numpy(forest_np)
+    ev = rdf.DecisionTreeEvaluator()
+    labels = rdf.DeviceArray((1, 480, 848), np.uint16).fill(65535)
+    ev.get_labels_forest(forest, rdf.to_device(frame), labels)
+    got = labels.get()
+    want = np.full((1, 480, 848), 65535, np.uint16)
+    oracle_np.eval_forest(frame, forest_np, want)
+    assert np.array_equal(got, want)
+    valid = (frame != 0) & (frame != 65535)
+    assert (got[~valid] == 65535).all() and got[valid].max() < 4 and 0.10 < valid.mean() < 0.20
+    # single-tree entry point on the same data (every walk reaches a leaf in the full topology)
+    tree = rdf.DecisionTree(10, 4)
+    tree.tree_out_cu.set(forest_np[0])
+    out = rdf.DeviceArray((1, 480, 848), np.uint16).fill(65535)
+    ev.get_labels(tree, rdf.to_device(frame), out)
+    assert np.array_equal(out.get(), want)
