@@ -47,6 +47,8 @@ class ShardedForestEvaluator:
         bounds = np.linspace(0, self.frames, n_chunks + 1).astype(int)
         self.chunks = [(int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
         # rank `dst` holds [world, frames, lh, lw]; everyone else only its own shard
+        self._step_no = 0
+        self._inflight = {}
         self.gathered = None
         if self.world > 1 and self.rank == dst:
             self.gathered = DeviceArray((self.world, self.frames, self.lh, self.lw), np.uint16)
@@ -78,6 +80,39 @@ class ShardedForestEvaluator:
         for w in works:
             w.wait()
         return works
+
+    # -- cross-step pipelining ----------------------------------------------------------------------
+    def step_overlapped(self, depth, labels_ring, prefill=None):
+        """One batch per call, ONE launch, and the gather of this step's label maps is left in flight: it
+        overlaps the NEXT step's evaluation (labels_ring = two output buffers used alternately).  Call
+        drain() before reading results or stopping the clock.  Steady state costs max(evaluate, gather)
+        per step instead of their sum, without splitting the batch into smaller launches."""
+        assert len(labels_ring) >= 2
+        slot = self._step_no % len(labels_ring)
+        labels = labels_ring[slot]
+        assert tuple(depth.shape) == (self.frames, self.h, self.w)
+        assert tuple(labels.shape) == (self.frames, self.lh, self.lw)
+        pending = self._inflight.get(slot)
+        if pending is not None:
+            pending.wait()          # the evaluation below must not overwrite a buffer that is still being sent
+            self._inflight[slot] = None
+        if prefill is not None:
+            labels.fill(prefill)
+        self.ev.get_labels_forest(self.forest, depth, labels, labels_reduce=self.r, scale_factor=self.s)
+        if self.world > 1:
+            send = self._torch_view(labels, 0, self.frames)
+            recv = None
+            if self.rank == self.dst:
+                recv = [self._torch_view(self.gathered[g], 0, self.frames) for g in range(self.world)]
+            self._inflight[slot] = self.dist.gather(send, recv, dst=self.dst, group=self.group, async_op=True)
+        self._step_no += 1
+        return labels
+
+    def drain(self):
+        for slot, w in list(self._inflight.items()):
+            if w is not None:
+                w.wait()
+                self._inflight[slot] = None
 
     def result(self):
         """Rank `dst`: DeviceArray [world*frames, lh, lw] of every rank's labels (world 1: None)."""

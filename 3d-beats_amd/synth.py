@@ -63,8 +63,9 @@ def frames(kinds, first_idx=0, h=480, w=848):
 
 
 def mixed_batch(n, first_idx=0, h=480, w=848):
-    """First half dense, second half live-like (config 4's 512 + 512 split applied per shard)."""
-    kinds = ["dense"] * (n - n // 2) + ["live"] * (n // 2)
+    """Half dense, half live-like (config 4's 512 + 512 split applied per shard), alternating, so that
+    every contiguous chunk of the batch carries the same mix."""
+    kinds = ["dense" if i % 2 == 0 else "live" for i in range(n)]
     return frames(kinds, first_idx, h, w)
 
 

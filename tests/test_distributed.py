@@ -39,11 +39,17 @@ def _worker(rank, world, port, n_chunks, tmpdir):
         mine = rdf.synth.mixed_batch(frames, first_idx=a, h=h, w=w)
         ev = rdf.DecisionTreeEvaluator()
         sh = dmod.ShardedForestEvaluator(ev, forest, frames, (h, w), labels_reduce=r, scale_factor=0.5,
-                                         n_chunks=n_chunks)
+                                         n_chunks=max(n_chunks, 1))
         depth = rdf.to_device(mine)
         labels = rdf.DeviceArray((frames, h // r, w // r), np.uint16)
-        for _ in range(2):
-            sh.step(depth, labels, prefill=65535)
+        if n_chunks == 0:      # cross-step pipelining: one launch per step, gather overlaps the next step
+            ring = [labels, rdf.DeviceArray((frames, h // r, w // r), np.uint16)]
+            for _ in range(3):
+                sh.step_overlapped(depth, ring, prefill=65535)
+            sh.drain()
+        else:
+            for _ in range(2):
+                sh.step(depth, labels, prefill=65535)
         dist.barrier()
         if rank == 0:
             got = sh.result().get()
@@ -60,7 +66,7 @@ def _worker(rank, world, port, n_chunks, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_chunks", [1, 3])
+@pytest.mark.parametrize("n_chunks", [1, 3, 0])
 def test_two_rank_gather_matches_oracle(n_chunks, tmp_path, oracle):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), n_chunks, str(tmp_path)), nprocs=2, join=True)
