@@ -11,11 +11,12 @@ inference path.
 from . import synth  # noqa: F401
 from ._lib import RdfError, library_path  # noqa: F401
 from .decision_tree import (DecisionForest, DecisionTree, DecisionTreeEvaluator,  # noqa: F401
-                            LayeredDecisionForest)
+                            DecisionTreeTrainer, LayeredDecisionForest)
 from .device import DeviceArray, HipRuntime, device_ptr, get_runtime, set_runtime, to_device  # noqa: F401
 from .engine.buffer import GpuBuffer  # noqa: F401
 from .util import MAX_UINT16  # noqa: F401
 
-__all__ = ["DecisionTree", "DecisionForest", "LayeredDecisionForest", "DecisionTreeEvaluator", "GpuBuffer",
+__all__ = ["DecisionTree", "DecisionForest", "LayeredDecisionForest", "DecisionTreeEvaluator", "DecisionTreeTrainer",
+           "GpuBuffer",
            "DeviceArray", "HipRuntime", "MAX_UINT16", "RdfError", "device_ptr", "get_runtime", "set_runtime",
            "to_device", "library_path", "synth"]

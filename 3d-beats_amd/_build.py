@@ -5,7 +5,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rdf_hip.hip")
-SOURCES = [SRC, os.path.join(HERE, "csrc", "mean_shift_hip.hip"), os.path.join(HERE, "csrc", "points_ops_hip.hip")]
+SOURCES = [SRC, os.path.join(HERE, "csrc", "mean_shift_hip.hip"), os.path.join(HERE, "csrc", "points_ops_hip.hip"),
+           os.path.join(HERE, "csrc", "tree_train_hip.hip")]
 HDR = os.path.join(HERE, "..", "include", "rdf_hip.h")
 SO = os.path.join(HERE, "csrc", "librdf_hip.so")
 

@@ -36,6 +36,14 @@ SIGNATURES = {
     "rdf_stencil_depth_image_by_group": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_flip_x": (_c_int, [_c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_make_rgba_from_labels": (_c_int, [_c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_train_init": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_train_histogram": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
+                                     _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "rdf_train_pick_best": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_train_next_active": (_c_int, [_c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_train_update_pixels": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
+                                         _c_void_p]),
     "rdf_fill_u16": (_c_int, [_c_void_p, _c_size_t, ctypes.c_uint16, _c_void_p]),
     "rdf_debug_floor_i32": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_debug_div_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

@@ -1,0 +1,429 @@
+// tree_train_hip.hip -- gfx950 kernels for training one randomized decision tree.
+//
+// Reference: src/cuda/tree_train.cu (evaluate_random_features :4-64, gini helpers :66-97,
+// pick_best_features :99-236, get_active_nodes_next_level :238-273, copy_pixel_groups :275-324) driven
+// level by level from src/decision_tree.py:444-600.  Not a translation:
+//   * the histogram kernel keeps one PIXEL per lane and loops over the proposals (wave-uniform, read
+//     through the scalar cache) with the pixel's depth neighbourhood staged in LDS, where the
+//     reference spends one thread and one 64-bit global atomic per (pixel, proposal);
+//   * when the pixels of a wave sit in the same node -- the rule on the upper levels -- the wave
+//     counts with ballots and popcounts and issues at most 2*C atomics per proposal, from distinct
+//     lanes to distinct bins; only mixed waves fall back to one atomic per lane;
+//   * the next level's node list is built by an ordered scan (the reference appends with an atomic
+//     counter, i.e. in scheduler order), so the whole training run is reproducible bit for bit;
+//   * floor((u)/d) uses the shared-reciprocal divide verified exhaustively for inference
+//     (tools/verify_fastdiv.hip) with the IEEE divide for numerators outside the verified range.
+// Counts are integers, so they are exact whatever the order; the fp32 gain arithmetic follows the
+// reference expression by expression (built with -ffp-contract=off).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rdf_hip.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kNoPixel = 65535u;
+constexpr int kHalo = 16;
+constexpr int kTW = 64 + 2 * kHalo;          // staged tile: 96 columns
+constexpr int kRows = 4;                      // one label row per wave, 4 waves
+constexpr int kTH = kRows + 2 * kHalo;        // 36 rows
+constexpr int kMaxClasses = 64;
+
+__device__ __forceinline__ int floor_i32(float f)
+{
+    int r;
+    const float fl = __builtin_floorf(f);
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(fl));
+    return r;
+}
+__device__ __forceinline__ int floor_i32_not_nan(float f)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+__device__ __forceinline__ int add_wrap(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ bool fast_divide_ok(float a)   // +-0 or biased exponent 40..230 (verify_fastdiv.hip)
+{
+    const uint32_t b = __float_as_uint(a);
+    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 190u;
+}
+
+// ---- root counts + nodes_by_pixel initialisation (decision_tree.py:452-468, done on the host there) ----
+__global__ __launch_bounds__(256) void k_train_init(const uint16_t *labels, size_t n_px, int C, int32_t *nodes, u64 *root)
+{
+    __shared__ unsigned int s_cnt[kMaxClasses];
+    if (threadIdx.x < kMaxClasses) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_px; i += (size_t)gridDim.x * 256) {
+        const uint32_t l = labels[i];
+        nodes[i] = l > 0u ? 0 : -1;
+        if (l > 0u && l < (uint32_t)C) atomicAdd(&s_cnt[l], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < C && s_cnt[threadIdx.x]) atomicAdd(root + threadIdx.x, (u64)s_cnt[threadIdx.x]);
+}
+
+struct HistArgs {
+    const uint16_t *depth, *labels;
+    const int32_t *nodes;
+    const float *props;   // [P][5]
+    u64 *counts;          // [P][NB][C]
+    uint32_t n_tiles, tiles_x, tiles_y;
+    int W, H, P, C, NB, node_start, node_end;
+};
+
+// evaluate_random_features (tree_train.cu:4-64)
+__global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
+{
+    __shared__ uint16_t s_tile[kTH * kTW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per_img = (uint32_t)a.W * (uint32_t)a.H;
+
+    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint32_t per = a.tiles_x * a.tiles_y;
+        const uint32_t img = tile / per, rem = tile - img * per;
+        const uint32_t ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        const int x = (int)(tx * 64u) + lane, y = (int)(ty * kRows) + wave;
+        const int tx0 = (int)(tx * 64u) - kHalo, ty0 = (int)(ty * kRows) - kHalo;
+        const size_t img_off = (size_t)img * per_img;
+
+        // does this tile hold any pixel that counts?  (most of a frame is unlabelled background)
+        int node = -1;
+        uint32_t label = 0u;
+        if (x < a.W && y < a.H) {
+            const size_t i = img_off + (size_t)y * a.W + x;
+            node = a.nodes[i];
+            if (node >= 0 && (node * 2 < a.node_start || node * 2 + 1 >= a.node_end)) node = -1;
+            if (node >= 0) label = a.labels[i];
+            if (label >= (uint32_t)a.C) node = -1;   // (the reference would index out of bounds)
+        }
+        if (!__syncthreads_or(node >= 0 ? 1 : 0)) continue;   // (also: the previous tile's readers are done)
+
+        for (int row = wave; row < kTH; row += 4) {
+            const int gy = ty0 + row;
+            const bool row_in = (uint32_t)gy < (uint32_t)a.H;
+            for (int col = lane; col < kTW; col += 64) {
+                const int gx = tx0 + col;
+                uint32_t v = kNoPixel;
+                if (row_in && (uint32_t)gx < (uint32_t)a.W) v = a.depth[img_off + (size_t)gy * a.W + gx];
+                s_tile[row * kTW + col] = (uint16_t)v;
+            }
+        }
+        __syncthreads();
+
+        const bool live = node >= 0;
+        if (!__any(live)) continue;   // wave-uniform; no barrier below this point in the iteration
+        const int xl = x - tx0, yl = y - ty0;
+        const uint32_t d = live ? s_tile[yl * kTW + xl] : 1u;
+        const float df = (float)(d == 0u ? 1u : d);
+        const float r0 = __builtin_amdgcn_rcpf(df);
+        const float rcp = __builtin_fmaf(__builtin_fmaf(-df, r0, 1.0f), r0, r0);
+        const bool zero_depth = d == 0u;              // compute_feature returns 0.f (decision_tree_common.hpp:12)
+
+        // wave-uniform node?  then count with ballots: masks per class, popcounts per proposal
+        const int node0 = __builtin_amdgcn_readfirstlane(__shfl(node, __ffsll((long long)__ballot(live)) - 1));
+        const bool uniform = a.C <= 32 && !__any(live && node != node0);
+        const u64 live_mask = __ballot(live);
+
+        auto side_of = [&](int j) -> bool {           // true = left (f < thresh)
+            const float *p = a.props + (size_t)j * 5;
+            const float ux = p[0], uy = p[1], vx = p[2], vy = p[3], thr = p[4];
+            int cux, cuy, cvx, cvy;
+            if (fast_divide_ok(ux) && fast_divide_ok(uy) && fast_divide_ok(vx) && fast_divide_ok(vy)) {
+                const f2 nu = {ux, uy}, nv = {vx, vy}, r2 = {rcp, rcp}, nd = {-df, -df};
+                const f2 qu0 = nu * r2, qv0 = nv * r2;
+                const f2 qu = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, qu0, nu), r2, qu0);
+                const f2 qv = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, qv0, nv), r2, qv0);
+                cux = add_wrap(xl, floor_i32_not_nan(qu.x)); cuy = add_wrap(yl, floor_i32_not_nan(qu.y));
+                cvx = add_wrap(xl, floor_i32_not_nan(qv.x)); cvy = add_wrap(yl, floor_i32_not_nan(qv.y));
+            } else {
+                cux = add_wrap(xl, floor_i32(ux / df)); cuy = add_wrap(yl, floor_i32(uy / df));
+                cvx = add_wrap(xl, floor_i32(vx / df)); cvy = add_wrap(yl, floor_i32(vy / df));
+            }
+            auto probe = [&](int cx, int cy) -> int {
+                if ((uint32_t)cx < (uint32_t)kTW && (uint32_t)cy < (uint32_t)kTH) return (int)s_tile[cy * kTW + cx];
+                const int gx = add_wrap(cx, tx0), gy = add_wrap(cy, ty0);
+                if ((uint32_t)gx < (uint32_t)a.W && (uint32_t)gy < (uint32_t)a.H)
+                    return (int)a.depth[img_off + (size_t)gy * a.W + gx];
+                return (int)kNoPixel;
+            };
+            const float f = zero_depth ? 0.0f : (float)(probe(cux, cuy) - probe(cvx, cvy));
+            return f < thr;
+        };
+
+        if (uniform) {
+            // class masks once; per proposal: left mask -> popcounts -> lane c adds left, lane C+c adds right
+            u64 cmask = 0ull;   // lanes c and C+c hold the mask of this wave's pixels of class c
+            for (int c = 0; c < a.C; ++c) {
+                const u64 m = __ballot(live && label == (uint32_t)c);
+                if (lane == c || lane == a.C + c) cmask = m;
+            }
+            const int child0 = node0 * 2 - a.node_start;
+            for (int j = 0; j < a.P; ++j) {
+                const u64 left = __ballot(live && side_of(j)) & live_mask;
+                if (lane < 2 * a.C) {
+                    const bool is_left = lane < a.C;
+                    const int c = is_left ? lane : lane - a.C;
+                    const unsigned n = (unsigned)__popcll(cmask & (is_left ? left : ~left));
+                    if (n) atomicAdd(a.counts + ((size_t)j * a.NB + (child0 + (is_left ? 0 : 1))) * a.C + c, (u64)n);
+                }
+            }
+        } else {
+            for (int j = 0; j < a.P; ++j) {
+                const bool left = side_of(j);
+                if (live) {
+                    const int child = node * 2 + (left ? 0 : 1) - a.node_start;
+                    atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + label, (u64)1);
+                }
+            }
+        }
+    }
+}
+
+// ---- gini helpers (tree_train.cu:66-97), fp32 exactly as written ----
+__device__ __forceinline__ u64 counts_sum(const u64 *p, int C)
+{
+    u64 s = 0;
+    for (int i = 0; i < C; ++i) s += p[i];
+    return s;
+}
+__device__ __forceinline__ float gini_impurity(const u64 *c, int C)
+{
+    const float s = (float)counts_sum(c, C) * 1.f;
+    float p = 0.f;
+    for (int i = 0; i < C; ++i) {
+        const float p_i = (float)c[i] / s;
+        p = p + p_i * p_i;
+    }
+    return 1 - p;
+}
+__device__ __forceinline__ float gini_gain(const u64 *pc, const u64 *lc, const u64 *rc, int C)
+{
+    const float p_sum = (float)counts_sum(pc, C);
+    const float p_imp = gini_impurity(pc, C);
+    const float rem = (((float)counts_sum(lc, C) / p_sum) * gini_impurity(lc, C)) +
+                      (((float)counts_sum(rc, C) / p_sum) * gini_impurity(rc, C));
+    return p_imp - rem;
+}
+__device__ __forceinline__ int count_above_cutoff(const u64 *c, int C, u64 sum, float cutoff)
+{
+    for (int i = 0; i < C; ++i)
+        if ((float)c[i] * 1.f / (float)sum >= cutoff) return i;
+    return -1;
+}
+
+// pick_best_features (tree_train.cu:99-236): one lane per active node
+__global__ __launch_bounds__(256) void k_train_pick_best(int n_active, const int32_t *active, int P, int D, int NB,
+                                                         int node_start, int node_end, int C, int level,
+                                                         const u64 *parent_counts, const u64 *by_feature,
+                                                         const float *props, float *tree, u64 *child_counts,
+                                                         float *best_gain)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_active) return;
+    const int E = 7 + 2 * C;
+    const int parent = active[i];
+    const int lchild = parent * 2, rchild = parent * 2 + 1;
+    if (lchild < node_start || rchild >= node_end) return;
+    const u64 *pc = parent_counts + (size_t)parent * C;
+    const u64 p_sum = counts_sum(pc, C);
+    const float prev = best_gain[i];
+
+    float best_g = -1.f;
+    int best_j = 0;
+    for (int j = 0; j < P; ++j) {
+        const u64 *lc = by_feature + ((size_t)j * NB + (lchild - node_start)) * C;
+        const u64 *rc = by_feature + ((size_t)j * NB + (rchild - node_start)) * C;
+        const u64 ls = counts_sum(lc, C), rs = counts_sum(rc, C);
+        const float g = (!ls || !rs) ? 0.f : gini_gain(pc, lc, rc, C);
+        if (g > best_g) { best_g = g; best_j = j; }
+    }
+    if (!(best_g > prev)) return;
+    best_gain[i] = best_g;
+
+    const u64 *lc = by_feature + ((size_t)best_j * NB + (lchild - node_start)) * C;
+    const u64 *rc = by_feature + ((size_t)best_j * NB + (rchild - node_start)) * C;
+    const u64 ls = counts_sum(lc, C), rs = counts_sum(rc, C);
+    float *rec = tree + ((size_t)((1 << level) - 1) + parent) * E;
+    for (int k = 0; k < 5; ++k) rec[k] = props[(size_t)best_j * 5 + k];
+
+    if (best_g <= 0.f) {   // no proposal separates anything: both sides end here with the parent's PDF
+        rec[5] = 0.f; rec[6] = 0.f;
+        for (int k = 0; k < C; ++k) {
+            const float p = ((float)pc[k] * 1.f) / (float)p_sum;
+            rec[7 + k] = p; rec[7 + C + k] = p;
+        }
+        return;
+    }
+    const float kCutoff = 0.999f;
+    for (int side = 0; side < 2; ++side) {
+        const u64 *cc = side ? rc : lc;
+        const u64 cs = side ? rs : ls;
+        const int cut = count_above_cutoff(cc, C, cs, kCutoff);
+        if (cut > -1) {
+            rec[5 + side] = 0.f;
+            rec[7 + side * C + cut] = 1.f;       // other entries keep whatever an earlier proposal block left
+        } else if (level == D - 1) {
+            rec[5 + side] = 0.f;
+            for (int n = 0; n < C; ++n) rec[7 + side * C + n] = ((float)cc[n] * 1.f) / (float)cs;
+        } else {
+            rec[5 + side] = -1.f;
+            u64 *dst = child_counts + (size_t)(side ? rchild : lchild) * C;
+            for (int n = 0; n < C; ++n) dst[n] = cc[n];
+        }
+    }
+}
+
+// get_active_nodes_next_level (tree_train.cu:238-273) as an ORDERED compaction: one workgroup, each thread a
+// contiguous run of active nodes, exclusive scan of the per-thread child counts, then the writes.
+__global__ __launch_bounds__(1024) void k_train_next_active(int level, int C, const float *tree, const int32_t *active,
+                                                            int n_active, int32_t *next_active, int32_t *n_next)
+{
+    __shared__ int s_cnt[1024];
+    const int E = 7 + 2 * C, t = threadIdx.x;
+    const int per = (n_active + 1023) / 1024;
+    const int b = t * per, e = min(b + per, n_active);
+    const size_t base = (size_t)((1 << level) - 1);
+    int cnt = 0;
+    for (int i = b; i < e; ++i) {
+        const float *rec = tree + (base + active[i]) * E;
+        cnt += (rec[5] == -1.f) + (rec[6] == -1.f);
+    }
+    s_cnt[t] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan
+        const int v = t >= o ? s_cnt[t - o] : 0;
+        __syncthreads();
+        s_cnt[t] += v;
+        __syncthreads();
+    }
+    int pos = s_cnt[t] - cnt;
+    for (int i = b; i < e; ++i) {
+        const int node = active[i];
+        const float *rec = tree + (base + node) * E;
+        if (rec[5] == -1.f) next_active[pos++] = node * 2;
+        if (rec[6] == -1.f) next_active[pos++] = node * 2 + 1;
+    }
+    if (t == 1023) *n_next = s_cnt[1023];
+}
+
+// copy_pixel_groups (tree_train.cu:275-324): route every live pixel through its node's chosen feature
+__global__ __launch_bounds__(256) void k_train_update_pixels(const uint16_t *depth, size_t n_px, int W, int H, int level,
+                                                             int C, int32_t *nodes, const float *tree)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_px) return;
+    const int parent = nodes[i];
+    if (parent == -1) return;
+    const size_t per = (size_t)W * H;
+    const size_t img_off = (i / per) * per;
+    const int y = (int)((i % per) / W), x = (int)((i % per) % W);
+    const float *rec = tree + ((size_t)((1 << level) - 1) + parent) * (7 + 2 * C);
+    const uint32_t d = depth[i];
+    float f = 0.f;
+    if (d != 0u) {
+        const float df = (float)d;
+        auto at = [&](float ox, float oy) -> float {
+            const int px = add_wrap(x, floor_i32(ox / df)), py = add_wrap(y, floor_i32(oy / df));
+            if ((uint32_t)px < (uint32_t)W && (uint32_t)py < (uint32_t)H) return (float)depth[img_off + (size_t)py * W + px];
+            return 65535.0f;
+        };
+        f = at(rec[0], rec[1]) - at(rec[2], rec[3]);
+    }
+    const bool left = f < rec[4];
+    const int status = floor_i32(rec[left ? 5 : 6]);
+    nodes[i] = status != -1 ? -1 : parent * 2 + (left ? 0 : 1);
+}
+
+} // namespace
+
+extern "C" {
+
+int rdf_train_init(const uint16_t *labels, size_t n_px, int n_classes, int32_t *nodes_by_pixel,
+                   unsigned long long *root_counts, void *stream)
+{
+    if (n_classes < 1 || n_classes > kMaxClasses) return RDF_ERR_BAD_ARG;
+    if (n_px == 0) return RDF_OK;
+    if (!labels || !nodes_by_pixel || !root_counts) return RDF_ERR_NULL_PTR;
+    size_t blocks = (n_px + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_train_init, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), labels, n_px,
+                       n_classes, nodes_by_pixel, root_counts);
+    return (int)hipGetLastError();
+}
+
+int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                        int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
+                        int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
+{
+    if (n_img < 0 || dim_x < 0 || dim_y < 0 || n_proposals < 0 || n_classes < 1 || n_classes > kMaxClasses ||
+        nodes_per_block < 1 || node_end - node_start > nodes_per_block || node_start < 0)
+        return RDF_ERR_BAD_ARG;
+    if ((long long)n_img * dim_x * dim_y >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    if (n_img == 0 || dim_x == 0 || dim_y == 0 || n_proposals == 0) return RDF_OK;
+    if (!depth || !labels || !nodes_by_pixel || !proposals || !counts) return RDF_ERR_NULL_PTR;
+    HistArgs a;
+    a.depth = depth; a.labels = labels; a.nodes = nodes_by_pixel; a.props = proposals; a.counts = counts;
+    a.W = dim_x; a.H = dim_y; a.P = n_proposals; a.C = n_classes; a.NB = nodes_per_block;
+    a.node_start = node_start; a.node_end = node_end;
+    a.tiles_x = (uint32_t)(dim_x + 63) / 64u;
+    a.tiles_y = (uint32_t)(dim_y + kRows - 1) / kRows;
+    const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
+    if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    a.n_tiles = (uint32_t)n_tiles;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long grid = (long long)cus * 8;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(k_train_histogram, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int rdf_train_pick_best(int n_active, const int32_t *active_nodes, int n_proposals, int max_depth, int nodes_per_block,
+                        int node_start, int node_end, int n_classes, int level,
+                        const unsigned long long *parent_counts, const unsigned long long *counts_by_feature,
+                        const float *proposals, float *tree_out, unsigned long long *child_counts,
+                        float *best_gain_per_node, void *stream)
+{
+    if (n_active < 0 || n_proposals < 0 || n_classes < 1 || n_classes > kMaxClasses || level < 0 || level >= max_depth ||
+        max_depth > 30)
+        return RDF_ERR_BAD_ARG;
+    if (n_active == 0 || n_proposals == 0) return RDF_OK;
+    if (!active_nodes || !parent_counts || !counts_by_feature || !proposals || !tree_out || !child_counts || !best_gain_per_node)
+        return RDF_ERR_NULL_PTR;
+    hipLaunchKernelGGL(k_train_pick_best, dim3((n_active + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       n_active, active_nodes, n_proposals, max_depth, nodes_per_block, node_start, node_end, n_classes, level,
+                       parent_counts, counts_by_feature, proposals, tree_out, child_counts, best_gain_per_node);
+    return (int)hipGetLastError();
+}
+
+int rdf_train_next_active(int level, int max_depth, int n_classes, const float *tree, const int32_t *active_nodes,
+                          int n_active, int32_t *next_active_nodes, int32_t *n_next_active, void *stream)
+{
+    if (level < 0 || level >= max_depth || max_depth > 30 || n_classes < 1 || n_active < 0) return RDF_ERR_BAD_ARG;
+    if (!n_next_active) return RDF_ERR_NULL_PTR;
+    if (n_active > 0 && (!tree || !active_nodes || !next_active_nodes)) return RDF_ERR_NULL_PTR;
+    hipLaunchKernelGGL(k_train_next_active, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), level, n_classes,
+                       tree, active_nodes, n_active, next_active_nodes, n_next_active);
+    return (int)hipGetLastError();
+}
+
+int rdf_train_update_pixels(const uint16_t *depth, int n_img, int dim_x, int dim_y, int level, int max_depth,
+                            int n_classes, int32_t *nodes_by_pixel, const float *tree, void *stream)
+{
+    if (n_img < 0 || dim_x < 0 || dim_y < 0 || level < 0 || level >= max_depth || max_depth > 30 || n_classes < 1)
+        return RDF_ERR_BAD_ARG;
+    const size_t n_px = (size_t)n_img * dim_x * dim_y;
+    if (n_px == 0) return RDF_OK;
+    if (n_px >= ((size_t)1 << 39)) return RDF_ERR_TOO_LARGE;
+    if (!depth || !nodes_by_pixel || !tree) return RDF_ERR_NULL_PTR;
+    hipLaunchKernelGGL(k_train_update_pixels, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), depth, n_px, dim_x, dim_y, level, n_classes, nodes_by_pixel, tree);
+    return (int)hipGetLastError();
+}
+
+} // extern "C"

@@ -284,6 +284,150 @@ class DecisionTreeEvaluator:
         return n
 
 
+# ---- training ---------------------------------------------------------------------------------
+FEATURE_MAGNITUDE_MAX = 14.   # decision_tree.py:353
+FEATURE_THRESHOLD_MAX = 11.   # _MIN = -_MAX
+
+
+def make_random_offset():
+    f_theta = np.random.uniform(0, np.pi * 2)
+    magnitude = np.power(np.e, np.random.uniform(0, FEATURE_MAGNITUDE_MAX))   # linear in log space
+    return np.array([np.cos(f_theta), np.sin(f_theta)]) * magnitude
+
+
+def make_random_feature():
+    return make_random_offset(), make_random_offset()
+
+
+def make_random_threshold():
+    return np.random.choice([-1, 1]) * np.power(np.e, np.random.uniform(0, FEATURE_THRESHOLD_MAX))
+
+
+def make_random_features(n, arr):
+    """n proposals (ux, uy, vx, vy, thresh) drawn from the global numpy RNG exactly as the reference draws them
+    (decision_tree.py:356-371), written into arr[n, 5] float32."""
+    rows = []
+    for _ in range(n):
+        (u, v), t = make_random_feature(), make_random_threshold()
+        rows.append((u[0], u[1], v[0], v[1], t))
+    arr[:] = np.array(rows, dtype=np.float32)
+
+
+class DecisionTreeTrainer:
+    """Level-synchronous trainer of one tree; constructor, allocate() and train() as in the reference
+    (decision_tree.py:373-600).  The training set stays resident in HBM (288 GB per GPU), so there are no
+    image blocks to stream and no nvcomp-compressed node maps: NUM_IMAGES_PER_IMAGE_BLOCK is accepted and
+    only checked for divisibility.  Proposal blocks and node blocks are kept: they decide which proposals
+    compete and are therefore part of the result."""
+
+    MAX_NEXT_NODES_TO_COUNT_PER_BLOCK = 2 ** 17   # decision_tree.py:424
+
+    def __init__(self, NUM_IMAGES_PER_IMAGE_BLOCK, NUM_PROPOSALS_PER_PROPOSAL_BLOCK):
+        self._rt = get_runtime()
+        self._lib = self._rt.lib
+        self.NUM_IMAGES_PER_IMAGE_BLOCK = NUM_IMAGES_PER_IMAGE_BLOCK
+        self.NUM_PROPOSALS_PER_PROPOSAL_BLOCK = NUM_PROPOSALS_PER_PROPOSAL_BLOCK
+
+    def allocate(self, dataset, NUM_RANDOM_FEATURES, MAX_TREE_DEPTH):
+        self.NUM_RANDOM_FEATURES = NUM_RANDOM_FEATURES
+        self.MAX_TREE_DEPTH = MAX_TREE_DEPTH
+        per_block = self.NUM_IMAGES_PER_IMAGE_BLOCK or dataset.num_images
+        assert dataset.num_images % per_block == 0
+        assert self.NUM_RANDOM_FEATURES % self.NUM_PROPOSALS_PER_PROPOSAL_BLOCK == 0
+        self.NUM_PROPOSAL_BLOCKS = self.NUM_RANDOM_FEATURES // self.NUM_PROPOSALS_PER_PROPOSAL_BLOCK
+        C = dataset.num_classes()
+        _, self.MAX_LEAF_NODES, _ = DecisionTree.get_config(MAX_TREE_DEPTH, C)
+        P = self.NUM_PROPOSALS_PER_PROPOSAL_BLOCK
+        shape = dataset.images_shape()
+        assert shape[0] * shape[1] * shape[2] < _PIX_LIMIT, "training set too large for one call"
+
+        self.node_counts_cu = DeviceArray((self.MAX_LEAF_NODES, C), np.uint64)
+        self.next_node_counts_cu = DeviceArray((self.MAX_LEAF_NODES, C), np.uint64)
+        self.active_nodes_cu = DeviceArray((self.MAX_LEAF_NODES,), np.int32)
+        self.next_active_nodes_cu = DeviceArray((self.MAX_LEAF_NODES,), np.int32)
+        self.next_num_active_nodes_cu = DeviceArray((1,), np.int32)
+        self.get_next_num_active_nodes = lambda: int(self.next_num_active_nodes_cu.get()[0])
+        self.best_gain_seen_per_node = DeviceArray((self.MAX_LEAF_NODES,), np.float32)
+        self.current_proposals_block_cpu = np.zeros((P, 5), dtype=np.float32)
+        self.current_proposals_block = DeviceArray((P, 5), np.float32)
+        self.nodes_per_block = min(self.MAX_LEAF_NODES, self.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK)
+        self.current_next_node_counts_by_feature_cu_block = DeviceArray((P, self.nodes_per_block, C), np.uint64)
+
+        # the whole training set, resident
+        self.depth_cu = DeviceArray(shape, np.uint16)
+        self.labels_cu = DeviceArray(shape, np.uint16)
+        self.nodes_by_pixel_cu = DeviceArray(shape, np.int32)
+        ipb = dataset.images_per_block
+        for b in range(dataset.num_images // ipb):
+            dataset.get_depth_block_cu(b, self.depth_cu[b * ipb:(b + 1) * ipb])
+            dataset.get_labels_block_cu(b, self.labels_cu[b * ipb:(b + 1) * ipb])
+
+    def train(self, dataset, tree):
+        lib, st = self._lib, self._rt.stream
+        C = dataset.num_classes()
+        n_img, dim_y, dim_x = self.depth_cu.shape
+        D = self.MAX_TREE_DEPTH
+        P = self.NUM_PROPOSALS_PER_PROPOSAL_BLOCK
+        NB = self.nodes_per_block
+        chk = lambda rc, what: _lib.check(lib, rc, what)
+
+        tree.tree_out_cu.fill(np.float32(0.))
+        self.node_counts_cu.fill(0)
+        self.next_node_counts_cu.fill(0)
+        chk(lib.rdf_train_init(self.labels_cu.ptr, self.labels_cu.size, C, self.nodes_by_pixel_cu.ptr,
+                               self.node_counts_cu.ptr, st()), "rdf_train_init")
+        self.next_node_counts_cu.copy_from(self.node_counts_cu)   # both start from the root counts (:399-400)
+
+        self.active_nodes_cu.fill(np.int32(0))          # one node to start, index 0
+        self.next_num_active_nodes_cu.fill(np.int32(1))
+
+        for current_level in range(D):
+            num_active_nodes = self.get_next_num_active_nodes()
+            if num_active_nodes == 0:
+                break
+            self.best_gain_seen_per_node.fill(np.float32(-1.))
+
+            for _ in range(self.NUM_PROPOSAL_BLOCKS):
+                make_random_features(P, self.current_proposals_block_cpu)
+                self.current_proposals_block.set(self.current_proposals_block_cpu)
+
+                max_active_nodes_next_level = 2 ** (current_level + 1)
+                if max_active_nodes_next_level > self.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK:
+                    n_node_blocks = max_active_nodes_next_level // self.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK
+                    node_blocks = [(i * self.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK, (i + 1) * self.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK)
+                                   for i in range(n_node_blocks)]
+                else:
+                    node_blocks = [(0, max_active_nodes_next_level)]
+
+                for node_block_start, node_block_end in node_blocks:
+                    self.current_next_node_counts_by_feature_cu_block.fill(0)
+                    chk(lib.rdf_train_histogram(self.depth_cu.ptr, self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr,
+                                                n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
+                                                node_block_start, node_block_end, NB,
+                                                self.current_next_node_counts_by_feature_cu_block.ptr, st()),
+                        "rdf_train_histogram")
+                    chk(lib.rdf_train_pick_best(num_active_nodes, self.active_nodes_cu.ptr, P, D, NB, node_block_start,
+                                                node_block_end, C, current_level, self.node_counts_cu.ptr,
+                                                self.current_next_node_counts_by_feature_cu_block.ptr,
+                                                self.current_proposals_block.ptr, device_ptr(tree.tree_out_cu),
+                                                self.next_node_counts_cu.ptr, self.best_gain_seen_per_node.ptr, st()),
+                        "rdf_train_pick_best")
+
+            self.next_num_active_nodes_cu.fill(np.int32(0))
+            self.next_active_nodes_cu.fill(np.int32(0))
+            chk(lib.rdf_train_next_active(current_level, D, C, device_ptr(tree.tree_out_cu), self.active_nodes_cu.ptr,
+                                          num_active_nodes, self.next_active_nodes_cu.ptr,
+                                          self.next_num_active_nodes_cu.ptr, st()), "rdf_train_next_active")
+            if current_level == D - 1:
+                break
+            self.node_counts_cu.copy_from(self.next_node_counts_cu)
+            chk(lib.rdf_train_update_pixels(self.depth_cu.ptr, n_img, dim_x, dim_y, current_level, D, C,
+                                            self.nodes_by_pixel_cu.ptr, device_ptr(tree.tree_out_cu), st()),
+                "rdf_train_update_pixels")
+            self.active_nodes_cu.copy_from(self.next_active_nodes_cu)
+        _touch(tree.tree_out_cu)
+
+
 def _image_chunks(num_images, pix_per_image):
     """Split a batch so that one C-ABI call addresses < 2^31 depth pixels."""
     if num_images <= 0 or pix_per_image <= 0:

@@ -50,6 +50,9 @@ class HipRuntime:
     def as_torch(self, handle, offset, nbytes):
         return handle[offset:offset + nbytes]
 
+    def d2d(self, dst, dst_off, src, src_off, nbytes):
+        dst[dst_off:dst_off + nbytes].copy_(src[src_off:src_off + nbytes], non_blocking=True)
+
     def fill_bytes(self, handle, offset, nbytes, pattern_u8):
         """Fill [offset, offset+nbytes) with a repeating little-endian element pattern."""
         lib = self.lib
@@ -154,6 +157,14 @@ class DeviceArray:
         assert a.size == self.size, f"size mismatch: {a.shape} vs {self.shape}"
         if self.nbytes:
             self._st.rt.h2d(self._st.handle, self._off, a.reshape(-1).view(np.uint8))
+        self._st.version += 1
+        return self
+
+    def copy_from(self, other):
+        """Device-to-device copy of an array of the same size and dtype (stream-ordered)."""
+        assert isinstance(other, DeviceArray) and other.dtype == self.dtype and other.size == self.size
+        if self.nbytes:
+            self._st.rt.d2d(self._st.handle, self._off, other._st.handle, other._off, self.nbytes)
         self._st.version += 1
         return self
 

@@ -168,6 +168,34 @@ int rdf_flip_x(int dim_x, int dim_y, const uint16_t *in, uint16_t *out, void *st
 int rdf_make_rgba_from_labels(int dim_x, int dim_y, int num_colors, const uint16_t *labels,
                               const uint8_t *colors_rgba, uint8_t *image_rgba, void *stream);
 
+/*
+ * ---- training of one tree; kernel parameters as in src/cuda/tree_train.cu ----
+ * rdf_train_init            root class counts + nodes_by_pixel = (label > 0 ? 0 : -1): the host-side set-up of
+ *                           src/decision_tree.py:452-468, on the device; root_counts[n_classes] must be zero
+ * rdf_train_histogram       evaluate_random_features, tree_train.cu:4-64: counts[j][child - node_start][label] += 1 for
+ *                           every live pixel whose children fall in [node_start, node_end); counts is uint64
+ *                           [n_proposals][nodes_per_block][n_classes], zeroed by the caller; proposals float32 [P][5]
+ * rdf_train_pick_best       pick_best_features, tree_train.cu:99-236 (same arguments)
+ * rdf_train_next_active     get_active_nodes_next_level, tree_train.cu:238-273, but in ascending order of the parents
+ *                           (the reference appends in scheduler order); *n_next_active is written on the device
+ * rdf_train_update_pixels   copy_pixel_groups, tree_train.cu:275-324
+ * All images of the training set are addressed in one call (no image blocks): n_img*dim_x*dim_y < 2^31.
+ */
+int rdf_train_init(const uint16_t *labels, size_t n_px, int n_classes, int32_t *nodes_by_pixel,
+                   unsigned long long *root_counts, void *stream);
+int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                        int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
+                        int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream);
+int rdf_train_pick_best(int n_active, const int32_t *active_nodes, int n_proposals, int max_depth, int nodes_per_block,
+                        int node_start, int node_end, int n_classes, int level,
+                        const unsigned long long *parent_counts, const unsigned long long *counts_by_feature,
+                        const float *proposals, float *tree_out, unsigned long long *child_counts,
+                        float *best_gain_per_node, void *stream);
+int rdf_train_next_active(int level, int max_depth, int n_classes, const float *tree, const int32_t *active_nodes,
+                          int n_active, int32_t *next_active_nodes, int32_t *n_next_active, void *stream);
+int rdf_train_update_pixels(const uint16_t *depth, int n_img, int dim_x, int dim_y, int level, int max_depth,
+                            int n_classes, int32_t *nodes_by_pixel, const float *tree, void *stream);
+
 /* GPUArray.fill(65535) of src/decision_tree.py:237-240 for uint16 buffers. */
 int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
 

@@ -111,6 +111,9 @@ class HostRuntime:
         else:
             handle[offset:offset + nbytes] = np.tile(pattern_u8, nbytes // pattern_u8.size)
 
+    def d2d(self, dst, dst_off, src, src_off, nbytes):
+        dst[dst_off:dst_off + nbytes] = src[src_off:src_off + nbytes]
+
     def as_torch(self, handle, offset, nbytes):
         import torch
         return torch.from_numpy(handle)[offset:offset + nbytes]
