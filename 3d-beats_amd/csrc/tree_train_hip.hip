@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/rdf_hip.h"
 
@@ -74,15 +75,30 @@ struct HistArgs {
     u64 *counts;          // [P][NB][C]
     uint32_t n_tiles, tiles_x, tiles_y;
     int W, H, P, C, NB, node_start, node_end;
+    int pj;               // LDSHIST: proposals per pass (LDS histogram of pj x (node_end-node_start) x C words)
 };
 
-// evaluate_random_features (tree_train.cu:4-64)
+// evaluate_random_features (tree_train.cu:4-64).
+// LDSHIST (upper levels, few child nodes): the workgroup keeps a private histogram of `pj` proposals in LDS over
+// ALL its tiles and adds it to the global one once per pass, which removes the same-address contention of the
+// few hot bins; otherwise every wave adds straight to global memory.
+template <bool LDSHIST>
 __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
 {
     __shared__ uint16_t s_tile[kTH * kTW];
+    extern __shared__ unsigned int s_hist[];   // LDSHIST: [pj][node_end - node_start][C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t per_img = (uint32_t)a.W * (uint32_t)a.H;
+    const int n_children = a.node_end - a.node_start;
+    const int hist_words = LDSHIST ? a.pj * n_children * a.C : 0;
 
+  for (int j0 = 0; j0 < a.P; j0 += (LDSHIST ? a.pj : a.P)) {
+    const int j1 = LDSHIST ? min(j0 + a.pj, a.P) : a.P;
+    if (LDSHIST) {
+        __syncthreads();
+        for (int i = tid; i < hist_words; i += 256) s_hist[i] = 0u;
+        __syncthreads();
+    }
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const uint32_t per = a.tiles_x * a.tiles_y;
         const uint32_t img = tile / per, rem = tile - img * per;
@@ -163,25 +179,41 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
                 if (lane == c || lane == a.C + c) cmask = m;
             }
             const int child0 = node0 * 2 - a.node_start;
-            for (int j = 0; j < a.P; ++j) {
+            for (int j = j0; j < j1; ++j) {
                 const u64 left = __ballot(live && side_of(j)) & live_mask;
                 if (lane < 2 * a.C) {
                     const bool is_left = lane < a.C;
                     const int c = is_left ? lane : lane - a.C;
                     const unsigned n = (unsigned)__popcll(cmask & (is_left ? left : ~left));
-                    if (n) atomicAdd(a.counts + ((size_t)j * a.NB + (child0 + (is_left ? 0 : 1))) * a.C + c, (u64)n);
+                    const int child = child0 + (is_left ? 0 : 1);
+                    if (n) {
+                        if (LDSHIST) atomicAdd(&s_hist[((j - j0) * n_children + child) * a.C + c], n);
+                        else atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + c, (u64)n);
+                    }
                 }
             }
         } else {
-            for (int j = 0; j < a.P; ++j) {
+            for (int j = j0; j < j1; ++j) {
                 const bool left = side_of(j);
                 if (live) {
                     const int child = node * 2 + (left ? 0 : 1) - a.node_start;
-                    atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + label, (u64)1);
+                    if (LDSHIST) atomicAdd(&s_hist[((j - j0) * n_children + child) * a.C + (int)label], 1u);
+                    else atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + label, (u64)1);
                 }
             }
         }
     }
+    if (LDSHIST) {   // one add per non-empty bin per workgroup and pass
+        __syncthreads();
+        for (int i = tid; i < hist_words; i += 256) {
+            const unsigned int v = s_hist[i];
+            if (v) {
+                const int jj = i / (n_children * a.C), rest = i - jj * (n_children * a.C);
+                atomicAdd(a.counts + ((size_t)(j0 + jj) * a.NB) * a.C + rest, (u64)v);
+            }
+        }
+    }
+  }
 }
 
 // ---- gini helpers (tree_train.cu:66-97), fp32 exactly as written ----
@@ -377,9 +409,24 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
     a.n_tiles = (uint32_t)n_tiles;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    long long grid = (long long)cus * 8;
-    if (grid > n_tiles) grid = n_tiles;
-    hipLaunchKernelGGL(k_train_histogram, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    // private LDS histogram while pj >= 8 proposals of (children x classes) words fit in 56 KB
+    const long long words_per_proposal = (long long)(node_end - node_start) * n_classes;
+    long long pj = (56 * 1024 / 4) / (words_per_proposal > 0 ? words_per_proposal : 1);
+    if (pj > n_proposals) pj = n_proposals;
+    const char *env = getenv("RDF_TRAIN_LDS_HIST");
+    const bool lds_hist = pj >= 8 && !(env && env[0] == '0');
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (lds_hist) {
+        a.pj = (int)pj;
+        long long grid = (long long)cus * 2;
+        if (grid > n_tiles) grid = n_tiles;
+        hipLaunchKernelGGL(k_train_histogram<true>, dim3((unsigned)grid), dim3(256), (size_t)(pj * words_per_proposal * 4), st, a);
+    } else {
+        a.pj = 0;
+        long long grid = (long long)cus * 8;
+        if (grid > n_tiles) grid = n_tiles;
+        hipLaunchKernelGGL(k_train_histogram<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    }
     return (int)hipGetLastError();
 }
 

@@ -18,6 +18,16 @@ import numpy as np
 
 
 class DecisionTreeDatasetConfig:
+    @staticmethod
+    def multiple(dataset_dir, images):
+        """Several datasets over one directory, e.g. [(n_train, per_block, 'train'), (n_test, None, 'test')]
+        (decision_tree.py:24-44).  Like the reference, every part draws its own random subset."""
+        with open(os.path.join(dataset_dir, 'config.json')) as fh:
+            total_images = json.loads(fh.read())['num_images']
+        assert sum(n for n, _, _ in images) <= total_images
+        return tuple(DecisionTreeDatasetConfig(dataset_dir, num_images=n, images_per_block=(per_block or n),
+                                               imgs_name=name) for n, per_block, name in images)
+
     def __init__(self, dataset_dir, num_images=0, images_per_block=0, imgs_name='data0', shuffle=True):
         self.dataset_dir = dataset_dir
         with open(os.path.join(dataset_dir, 'config.json')) as fh:
@@ -137,3 +147,49 @@ def evaluate_saved_model(model_path, dataset_dir, num_images, out_dir=None):
         for i in range(ds.num_images):
             Image.fromarray(render[i]).save(os.path.join(out_dir, f'eval_labels_{str(i).zfill(8)}.png'))
     return pct
+
+
+def train_forest(dataset_dir, num_train, num_test, proposals, proposals_block, out_trees, max_depth, out_path=None,
+                 trees_to_try=None, train_block=None, log=print):
+    """The flow of src/train_model.py:52-139 without its GLFW window: train `trees_to_try` candidate trees, keep
+    the `out_trees` best by test accuracy, evaluate the forest, save it as the reference's .npy."""
+    from .decision_tree import DecisionForest, DecisionTree, DecisionTreeEvaluator, DecisionTreeTrainer
+    from .device import DeviceArray
+    from .util import MAX_UINT16
+    trees_to_try = trees_to_try or out_trees
+    train_data, test_data = DecisionTreeDatasetConfig.multiple(dataset_dir, [(num_train, train_block, 'train'),
+                                                                             (num_test, None, 'test')])
+    trainer = DecisionTreeTrainer(train_block or num_train, proposals_block)
+    evaluator = DecisionTreeEvaluator()
+    tree1 = DecisionTree(max_depth, train_data.num_classes())
+    trainer.allocate(train_data, proposals, tree1.max_depth)
+    out_cu = DeviceArray(test_data.images_shape(), np.uint16)
+    test_depth, test_labels = DeviceArray(test_data.images_shape(), np.uint16), DeviceArray(test_data.images_shape(), np.uint16)
+    test_data.get_depth_block_cu(0, test_depth)
+    test_data.get_labels_block_cu(0, test_labels)
+    truth = test_labels.get()
+    best = [None] * out_trees
+    forest_cpu = np.zeros((out_trees, tree1.TOTAL_TREE_NODES, tree1.TREE_NODE_ELS), dtype=np.float32)
+    for i in range(trees_to_try):
+        trainer.train(train_data, tree1)
+        out_cu.fill(MAX_UINT16)
+        evaluator.get_labels(tree1, test_depth, out_cu)
+        pct = float(np.sum(out_cu.get() == truth) / np.sum(truth > 0))
+        log(f'tree {i}: pct. matching pixels: {pct:.4f}')
+        slot = -1
+        if None in best:
+            slot = best.index(None)
+        elif pct > min(best):
+            slot = best.index(min(best))
+        if slot > -1:
+            best[slot] = pct
+            forest_cpu[slot] = tree1.tree_out_cu.get()
+    forest = DecisionForest(out_trees, max_depth, test_data.num_classes())
+    forest.forest_cu.set(forest_cpu)
+    out_cu.fill(MAX_UINT16)
+    evaluator.get_labels_forest(forest, test_depth, out_cu)
+    pct = float(np.sum(out_cu.get() == truth) / np.sum(truth > 0))
+    log(f'FOREST pct. matching pixels: {pct:.4f}')
+    if out_path:
+        np.save(out_path, forest_cpu)
+    return forest_cpu, pct

@@ -100,3 +100,20 @@ def test_proposal_generator_matches_restatement(rdf):
     np.random.seed(123)
     b = tn.make_random_features(9)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_train_forest_flow_from_a_dataset_directory(rdf, gpu_runtime, tmp_path):
+    """train_model.py's flow end to end: dataset directory -> candidate trees -> best trees -> forest .npy that the
+    inference path loads and that beats chance on held-out frames."""
+    ds_mod = importlib.import_module("3d-beats_amd.dataset")
+    depth, labels = make_data(rdf, n=10, h=48, w=64, first=300)
+    ddir = tmp_path / "data"
+    ds_mod.write_dataset(str(ddir), depth, labels, {1: [255, 0, 0, 255], 2: [0, 255, 0, 255], 3: [0, 0, 255, 255]})
+    np.random.seed(5)
+    out = tmp_path / "forest.npy"
+    forest_cpu, pct = ds_mod.train_forest(str(ddir), 6, 4, 32, 16, 2, 6, str(out), trees_to_try=3, log=lambda *_: None)
+    assert forest_cpu.shape == (2, 63, 15) and out.exists()
+    assert pct > 0.5
+    f = rdf.DecisionForest.load(str(out))
+    assert (f.num_trees, f.max_depth, f.num_classes) == (2, 6, 4)
