@@ -6,14 +6,17 @@
 //     that kGroup node fetches and 2*kGroup depth probes are in flight per lane (the reference
 //     uses one thread per (pixel,tree), shared-memory float atomics and two block barriers);
 //   * a wave is 64 consecutive label pixels of one row; a workgroup owns a 2-D tile (64 columns x
-//     4 rows per wave, rows of the waves interleaved) so that the probe neighbourhoods of its waves
-//     overlap in the CU's L1; the centre-depth read and the label store are one 128-byte line;
+//     4 rows per wave, rows of the waves interleaved) whose depth neighbourhood it stages in LDS;
+//     the label store is one 128-byte line;
 //   * per-tree leaf PDFs are added in registers in tree order (canonical order, no atomics);
 //   * node records are 16 bytes {int24 floor(s*u), int24 floor(s*v), integer threshold, flags}:
 //     the top levels of every tree live in LDS, deeper levels are ONE 128-bit load each from the
 //     packed table (rdf_forest_pack) or, for the unpacked entry point, the reference's own
-//     7+2C-float records.  The kernel is bound by the L1 tag rate (one cache line per clock per
-//     CU, profiles/), so what counts is lines touched per wave instruction, not bytes;
+//     7+2C-float records.  An earlier version with two loads per node was bound by the L1 tag rate
+//     (one cache line per clock per CU, profiles/): what counts is lines touched per wave
+//     instruction, not bytes.  The current version is bound by VALU issue;
+//   * all probes of a level are issued before any is consumed: nothing waits inside a divergent
+//     branch (an earlier version serialised eight global round trips per level that way);
 //   * the workgroup's depth tile plus a halo is staged in LDS (out-of-image cells = 65535), so
 //     most probes are LDS reads with no bounds check; far probes go to global memory;
 //   * tiles are handed to persistent workgroups by a device-side queue (one atomic per tile), so
