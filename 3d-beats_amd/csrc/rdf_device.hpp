@@ -1,0 +1,98 @@
+// rdf_device.hpp -- device helpers shared by the forest-evaluation and the training kernels:
+// the reference's __float2int_rd, wrapping coordinate adds, the verified shared-reciprocal divide and the
+// two-source depth probe (staged LDS tile / global memory).
+#ifndef RDF_DEVICE_HPP
+#define RDF_DEVICE_HPP
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr uint32_t kNoPixel = 65535u;
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// __float2int_rd: floor, then saturating convert with NaN -> 0 (v_floor_f32 + v_cvt_i32_f32).
+// The fused v_cvt_flr_i32_f32 is NOT equivalent: measured on gfx950 it maps NaN to INT_MAX.
+// The convert is inline asm because a C++ float->int cast is undefined outside int range.
+__device__ __forceinline__ int floor_i32(float f)
+{
+    int r;
+    const float fl = __builtin_floorf(f);
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(fl));
+    return r;
+}
+
+// Same result for every non-NaN input (checked on gfx950, tests/test_gpu_parity.py); one VALU op.
+__device__ __forceinline__ int floor_i32_not_nan(float f)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
+__device__ __forceinline__ int add_wrap(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+
+// floor((a.x)/d), floor((a.y)/d) for a pair of numerators with the pixel's refined reciprocal rcp2 = (r, r),
+// ndf2 = (-d, -d): q0 = a*r; rem = a - d*q0 (exact, fma); q = q0 + rem*r.  Equal to the IEEE divide in
+// floor-to-int for every depth 1..65535 and every numerator that is +-0 or has a biased exponent in
+// [40, 230] (tools/verify_fastdiv.hip, exhaustive on gfx950).  Packed f32: two quotients per instruction.
+__device__ __forceinline__ f2 fast_quotient2(f2 a, f2 rcp2, f2 ndf2)
+{
+    const f2 q0 = a * rcp2;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(ndf2, q0, a), rcp2, q0);
+}
+
+__device__ __forceinline__ bool fast_divide_ok(float a)   // the verified numerator range
+{
+    const uint32_t b = __float_as_uint(a);
+    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 190u;
+}
+
+// A depth probe at (x, y) of the current image is answered by the staged LDS tile when the coordinate
+// falls inside it (cells outside the image already hold 65535), else by global memory with the
+// per-axis bounds check of cu_utils.hpp:79-86.  The loads are only ISSUED here; their values are
+// consumed after all probes of the level have been issued, so every probe of a level is in flight
+// together and nothing waits inside a divergent branch (an earlier version waited vmcnt(0) per probe).  `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets
+// (a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is < 2^24 when used).
+struct ProbeCtx {
+    const uint16_t *tile;   // LDS
+    const char *depth_b;
+    uint32_t img_boff;
+    int tx0, ty0, tw, th, twp, W, H;
+};
+
+struct Probe {
+    uint32_t lds_v, glb_v;   // the two candidate values
+    bool in_tile, inb;
+};
+
+// (cx, cy) = probe position RELATIVE TO THE STAGED TILE (the caller adds the offsets to the pixel's own
+// tile-relative position); image coordinates are only rebuilt for lanes that leave the tile.
+__device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int cx, int cy)
+{
+    Probe p;
+    p.in_tile = (uint32_t)cx < (uint32_t)c.tw && (uint32_t)cy < (uint32_t)c.th;
+    const uint32_t li = p.in_tile ? __umul24((uint32_t)cy, (uint32_t)c.twp) + (uint32_t)cx : 0u;
+    p.lds_v = c.tile[li];
+    p.glb_v = 0u;
+    p.inb = false;
+    if (!p.in_tile) {
+        const int x = add_wrap(cx, c.tx0), y = add_wrap(cy, c.ty0);
+        p.inb = (uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H;
+        if (p.inb) {   // only far lanes touch global memory; the value is consumed after the branch
+            const uint32_t go = (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1;
+            p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
+        }
+    }
+    return p;
+}
+
+__device__ __forceinline__ int probe_value(const Probe &p)
+{
+    return (int)(p.in_tile ? p.lds_v : (p.inb ? p.glb_v : kNoPixel));
+}
+
+} // namespace
+
+#endif // RDF_DEVICE_HPP

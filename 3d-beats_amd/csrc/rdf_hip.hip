@@ -39,6 +39,7 @@
 #include <utility>
 
 #include "../../include/rdf_hip.h"
+#include "rdf_device.hpp"
 
 namespace {
 
@@ -46,11 +47,8 @@ constexpr int kGroup = 4;          // trees walked interleaved by one lane
 constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
 constexpr int kDefaultLdsBudget = 40000;   // node table + depth tile per workgroup
 constexpr int kDefaultHalo = 16;   // depth pixels staged around a tile's centres
-constexpr uint32_t kNoPixel = 65535u;
 constexpr uint32_t kFlagLeft = 1u, kFlagRight = 2u, kFlagExact = 4u;
 constexpr int kSchedSlots = 256;
-
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Dynamic tile queue state, one slot per (device, stream) in use: {next tile, workgroups finished}.
 // Zero at rest: the last workgroup of a launch resets its slot, so launches need no memset and
@@ -109,27 +107,6 @@ struct EvalArgs {
     int fill_untouched;    // fused pre-fill: write 65535 to every label pixel that is not evaluated
     float s;
 };
-
-// __float2int_rd: floor, then saturating convert with NaN -> 0 (v_floor_f32 + v_cvt_i32_f32).
-// The fused v_cvt_flr_i32_f32 is NOT equivalent: measured on gfx950 it maps NaN to INT_MAX.
-// The convert is inline asm because a C++ float->int cast is undefined outside int range.
-__device__ __forceinline__ int floor_i32(float f)
-{
-    int r;
-    const float fl = __builtin_floorf(f);
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(fl));
-    return r;
-}
-
-// Same result for every non-NaN input (checked on gfx950, tests/test_gpu_parity.py); one VALU op.
-__device__ __forceinline__ int floor_i32_not_nan(float f)
-{
-    int r;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
-    return r;
-}
-
-__device__ __forceinline__ int add_wrap(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
 
 // floor(x) == -1  <=>  -1 <= x < 0   (NaN: false).  tree_eval.cu:101-102 / :186-187.
 __device__ __forceinline__ uint32_t child_flags(float l, float r)
@@ -198,50 +175,6 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
     n.t = (int)__builtin_amdgcn_perm(w.z, lo, 0x0b070100u);
     n.flags = w.w >> 24;
     return n;
-}
-
-// A depth probe at (x, y) of the current image is answered by the staged LDS tile when the coordinate
-// falls inside it (cells outside the image already hold 65535), else by global memory with the
-// per-axis bounds check of cu_utils.hpp:79-86.  The loads are only ISSUED here; their values are
-// consumed after all probes of the level have been issued, so every probe of a level is in flight
-// together and nothing waits inside a divergent branch (an earlier version waited vmcnt(0) per probe).  `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets
-// (a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is < 2^24 when used).
-struct ProbeCtx {
-    const uint16_t *tile;   // LDS
-    const char *depth_b;
-    uint32_t img_boff;
-    int tx0, ty0, tw, th, twp, W, H;
-};
-
-struct Probe {
-    uint32_t lds_v, glb_v;   // the two candidate values
-    bool in_tile, inb;
-};
-
-// (cx, cy) = probe position RELATIVE TO THE STAGED TILE (the caller adds the offsets to the pixel's own
-// tile-relative position); image coordinates are only rebuilt for lanes that leave the tile.
-__device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int cx, int cy)
-{
-    Probe p;
-    p.in_tile = (uint32_t)cx < (uint32_t)c.tw && (uint32_t)cy < (uint32_t)c.th;
-    const uint32_t li = p.in_tile ? __umul24((uint32_t)cy, (uint32_t)c.twp) + (uint32_t)cx : 0u;
-    p.lds_v = c.tile[li];
-    p.glb_v = 0u;
-    p.inb = false;
-    if (!p.in_tile) {
-        const int x = add_wrap(cx, c.tx0), y = add_wrap(cy, c.ty0);
-        p.inb = (uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H;
-        if (p.inb) {   // only far lanes touch global memory; the value is consumed after the branch
-            const uint32_t go = (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1;
-            p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
-        }
-    }
-    return p;
-}
-
-__device__ __forceinline__ int probe_value(const Probe &p)
-{
-    return (int)(p.in_tile ? p.lds_v : (p.inb ? p.glb_v : kNoPixel));
 }
 
 // FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise

@@ -21,37 +21,17 @@
 #include <stdlib.h>
 
 #include "../../include/rdf_hip.h"
+#include "rdf_device.hpp"
 
 namespace {
 
 typedef unsigned long long u64;
-typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr uint32_t kNoPixel = 65535u;
 constexpr int kHalo = 16;
 constexpr int kTW = 64 + 2 * kHalo;          // staged tile: 96 columns
 constexpr int kRows = 4;                      // one label row per wave, 4 waves
 constexpr int kTH = kRows + 2 * kHalo;        // 36 rows
 constexpr int kMaxClasses = 64;
-
-__device__ __forceinline__ int floor_i32(float f)
-{
-    int r;
-    const float fl = __builtin_floorf(f);
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(fl));
-    return r;
-}
-__device__ __forceinline__ int floor_i32_not_nan(float f)
-{
-    int r;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
-    return r;
-}
-__device__ __forceinline__ int add_wrap(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
-__device__ __forceinline__ bool fast_divide_ok(float a)   // +-0 or biased exponent 40..230 (verify_fastdiv.hip)
-{
-    const uint32_t b = __float_as_uint(a);
-    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 190u;
-}
+constexpr int kBatch = 4;                     // proposals evaluated together: 8 probes in flight per lane
 
 // ---- root counts + nodes_by_pixel initialisation (decision_tree.py:452-468, done on the host there) ----
 __global__ __launch_bounds__(256) void k_train_init(const uint16_t *labels, size_t n_px, int C, int32_t *nodes, u64 *root)
@@ -91,6 +71,14 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
     const uint32_t per_img = (uint32_t)a.W * (uint32_t)a.H;
     const int n_children = a.node_end - a.node_start;
     const int hist_words = LDSHIST ? a.pj * n_children * a.C : 0;
+
+    // Are all numerators of all proposals inside the range the shared-reciprocal divide is verified for?  (They
+    // are, for anything make_random_features draws.)  Decided once per workgroup: testing 4 numerators per
+    // proposal per wave in the loop below made the kernel scalar-ALU bound.
+    bool mine_ok = true;
+    for (int i = tid; i < a.P * 5; i += 256)
+        if (i % 5 != 4) mine_ok = mine_ok && fast_divide_ok(a.props[i]);
+    const bool all_fast = __syncthreads_and(mine_ok ? 1 : 0) != 0;
 
   for (int j0 = 0; j0 < a.P; j0 += (LDSHIST ? a.pj : a.P)) {
     const int j1 = LDSHIST ? min(j0 + a.pj, a.P) : a.P;
@@ -145,58 +133,62 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
         const bool uniform = a.C <= 32 && !__any(live && node != node0);
         const u64 live_mask = __ballot(live);
 
-        auto side_of = [&](int j) -> bool {           // true = left (f < thresh)
-            const float *p = a.props + (size_t)j * 5;
-            const float ux = p[0], uy = p[1], vx = p[2], vy = p[3], thr = p[4];
-            int cux, cuy, cvx, cvy;
-            if (fast_divide_ok(ux) && fast_divide_ok(uy) && fast_divide_ok(vx) && fast_divide_ok(vy)) {
-                const f2 nu = {ux, uy}, nv = {vx, vy}, r2 = {rcp, rcp}, nd = {-df, -df};
-                const f2 qu0 = nu * r2, qv0 = nv * r2;
-                const f2 qu = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, qu0, nu), r2, qu0);
-                const f2 qv = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, qv0, nv), r2, qv0);
-                cux = add_wrap(xl, floor_i32_not_nan(qu.x)); cuy = add_wrap(yl, floor_i32_not_nan(qu.y));
-                cvx = add_wrap(xl, floor_i32_not_nan(qv.x)); cvy = add_wrap(yl, floor_i32_not_nan(qv.y));
-            } else {
-                cux = add_wrap(xl, floor_i32(ux / df)); cuy = add_wrap(yl, floor_i32(uy / df));
-                cvx = add_wrap(xl, floor_i32(vx / df)); cvy = add_wrap(yl, floor_i32(vy / df));
-            }
-            auto probe = [&](int cx, int cy) -> int {
-                if ((uint32_t)cx < (uint32_t)kTW && (uint32_t)cy < (uint32_t)kTH) return (int)s_tile[cy * kTW + cx];
-                const int gx = add_wrap(cx, tx0), gy = add_wrap(cy, ty0);
-                if ((uint32_t)gx < (uint32_t)a.W && (uint32_t)gy < (uint32_t)a.H)
-                    return (int)a.depth[img_off + (size_t)gy * a.W + gx];
-                return (int)kNoPixel;
-            };
-            const float f = zero_depth ? 0.0f : (float)(probe(cux, cuy) - probe(cvx, cvy));
-            return f < thr;
-        };
+        const ProbeCtx pc = {s_tile, reinterpret_cast<const char *>(a.depth), (uint32_t)(img_off * 2), tx0, ty0, kTW, kTH, kTW,
+                             a.W, a.H};
+        const f2 r2 = {rcp, rcp}, nd = {-df, -df};
 
+        // kBatch proposals at a time: all their probes are issued before any is consumed (a far probe is a
+        // global round trip; waiting for each one inside its branch made this kernel 10x slower)
+        u64 cmask = 0ull;   // lanes c and C+c hold the mask of this wave's pixels of class c (uniform-node path)
         if (uniform) {
-            // class masks once; per proposal: left mask -> popcounts -> lane c adds left, lane C+c adds right
-            u64 cmask = 0ull;   // lanes c and C+c hold the mask of this wave's pixels of class c
             for (int c = 0; c < a.C; ++c) {
                 const u64 m = __ballot(live && label == (uint32_t)c);
                 if (lane == c || lane == a.C + c) cmask = m;
             }
-            const int child0 = node0 * 2 - a.node_start;
-            for (int j = j0; j < j1; ++j) {
-                const u64 left = __ballot(live && side_of(j)) & live_mask;
-                if (lane < 2 * a.C) {
-                    const bool is_left = lane < a.C;
-                    const int c = is_left ? lane : lane - a.C;
-                    const unsigned n = (unsigned)__popcll(cmask & (is_left ? left : ~left));
-                    const int child = child0 + (is_left ? 0 : 1);
-                    if (n) {
-                        if (LDSHIST) atomicAdd(&s_hist[((j - j0) * n_children + child) * a.C + c], n);
-                        else atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + c, (u64)n);
-                    }
+        }
+        const int child0 = node0 * 2 - a.node_start;
+
+        for (int jb = j0; jb < j1; jb += kBatch) {
+            Probe pu[kBatch], pv[kBatch];
+            float thr[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int j = min(jb + k, j1 - 1);               // tail: repeat the last proposal, result unused
+                const float *p = a.props + (size_t)j * 5;
+                const float ux = p[0], uy = p[1], vx = p[2], vy = p[3];
+                thr[k] = p[4];
+                int cux, cuy, cvx, cvy;
+                if (all_fast || (fast_divide_ok(ux) && fast_divide_ok(uy) && fast_divide_ok(vx) && fast_divide_ok(vy))) {   // wave-uniform
+                    const f2 qu = fast_quotient2(f2{ux, uy}, r2, nd), qv = fast_quotient2(f2{vx, vy}, r2, nd);
+                    cux = add_wrap(xl, floor_i32_not_nan(qu.x)); cuy = add_wrap(yl, floor_i32_not_nan(qu.y));
+                    cvx = add_wrap(xl, floor_i32_not_nan(qv.x)); cvy = add_wrap(yl, floor_i32_not_nan(qv.y));
+                } else {
+                    cux = add_wrap(xl, floor_i32(ux / df)); cuy = add_wrap(yl, floor_i32(uy / df));
+                    cvx = add_wrap(xl, floor_i32(vx / df)); cvy = add_wrap(yl, floor_i32(vy / df));
                 }
+                pu[k] = probe_issue(pc, cux, cuy);
+                pv[k] = probe_issue(pc, cvx, cvy);
             }
-        } else {
-            for (int j = j0; j < j1; ++j) {
-                const bool left = side_of(j);
-                if (live) {
-                    const int child = node * 2 + (left ? 0 : 1) - a.node_start;
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int j = jb + k;
+                if (j >= j1) break;                              // wave-uniform
+                const float f = zero_depth ? 0.0f : (float)(probe_value(pu[k]) - probe_value(pv[k]));
+                const bool is_left_px = f < thr[k];              // tree_train.cu:57-58
+                if (uniform) {
+                    const u64 left = __ballot(live && is_left_px) & live_mask;
+                    if (lane < 2 * a.C) {
+                        const bool is_left = lane < a.C;
+                        const int c = is_left ? lane : lane - a.C;
+                        const unsigned n = (unsigned)__popcll(cmask & (is_left ? left : ~left));
+                        const int child = child0 + (is_left ? 0 : 1);
+                        if (n) {
+                            if (LDSHIST) atomicAdd(&s_hist[((j - j0) * n_children + child) * a.C + c], n);
+                            else atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + c, (u64)n);
+                        }
+                    }
+                } else if (live) {
+                    const int child = node * 2 + (is_left_px ? 0 : 1) - a.node_start;
                     if (LDSHIST) atomicAdd(&s_hist[((j - j0) * n_children + child) * a.C + (int)label], 1u);
                     else atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + label, (u64)1);
                 }
