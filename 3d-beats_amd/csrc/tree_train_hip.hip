@@ -55,22 +55,17 @@ struct HistArgs {
     u64 *counts;          // [P][NB][C]
     uint32_t n_tiles, tiles_x, tiles_y;
     int W, H, P, C, NB, node_start, node_end;
-    int pj;               // LDSHIST: proposals per pass (LDS histogram of pj x (node_end-node_start) x C words)
 };
 
 // evaluate_random_features (tree_train.cu:4-64).
-// LDSHIST (upper levels, few child nodes): the workgroup keeps a private histogram of `pj` proposals in LDS over
-// ALL its tiles and adds it to the global one once per pass, which removes the same-address contention of the
-// few hot bins; otherwise every wave adds straight to global memory.
-template <bool LDSHIST>
+// Counts go straight to the global histogram, aggregated per wave first (see "peers" below).  A workgroup-
+// private LDS histogram for the upper levels was measured and dropped: with the per-wave aggregation it was
+// no faster at any level (r01 notes in DESIGN.md).
 __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
 {
     __shared__ uint16_t s_tile[kTH * kTW];
-    extern __shared__ unsigned int s_hist[];   // LDSHIST: [pj][node_end - node_start][C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t per_img = (uint32_t)a.W * (uint32_t)a.H;
-    const int n_children = a.node_end - a.node_start;
-    const int hist_words = LDSHIST ? a.pj * n_children * a.C : 0;
 
     // Are all numerators of all proposals inside the range the shared-reciprocal divide is verified for?  (They
     // are, for anything make_random_features draws.)  Decided once per workgroup: testing 4 numerators per
@@ -80,13 +75,7 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
         if (i % 5 != 4) mine_ok = mine_ok && fast_divide_ok(a.props[i]);
     const bool all_fast = __syncthreads_and(mine_ok ? 1 : 0) != 0;
 
-  for (int j0 = 0; j0 < a.P; j0 += (LDSHIST ? a.pj : a.P)) {
-    const int j1 = LDSHIST ? min(j0 + a.pj, a.P) : a.P;
-    if (LDSHIST) {
-        __syncthreads();
-        for (int i = tid; i < hist_words; i += 256) s_hist[i] = 0u;
-        __syncthreads();
-    }
+    const int j0 = 0, j1 = a.P;
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const uint32_t per = a.tiles_x * a.tiles_y;
         const uint32_t img = tile / per, rem = tile - img * per;
@@ -128,10 +117,21 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
         const float rcp = __builtin_fmaf(__builtin_fmaf(-df, r0, 1.0f), r0, r0);
         const bool zero_depth = d == 0u;              // compute_feature returns 0.f (decision_tree_common.hpp:12)
 
-        // wave-uniform node?  then count with ballots: masks per class, popcounts per proposal
-        const int node0 = __builtin_amdgcn_readfirstlane(__shfl(node, __ffsll((long long)__ballot(live)) - 1));
-        const bool uniform = a.C <= 32 && !__any(live && node != node0);
+        // Lanes that share (node, class) form a group; per proposal each group splits into a left and a right
+        // part and only the lowest lane of each part adds the part's size.  That is the fewest atomics a wave
+        // can issue without knowing the bins in advance: one per (node, class, side) it touches instead of one
+        // per pixel (deep levels were bound by ~1e9 global atomics per level before).
         const u64 live_mask = __ballot(live);
+        const int key = node * a.C + (int)label;
+        u64 peers = 0ull;
+        for (u64 todo = live_mask; todo;) {               // wave-uniform loop, once per tile
+            const int src = __ffsll((long long)todo) - 1;
+            const int k0 = __builtin_amdgcn_readfirstlane(__shfl(key, src));
+            const u64 m = __ballot(live && key == k0);
+            if (key == k0) peers = m;
+            todo &= ~m;
+        }
+        const int bin0 = (node * 2 - a.node_start) * a.C + (int)label;   // left child's bin; right child's is + C
 
         const ProbeCtx pc = {s_tile, reinterpret_cast<const char *>(a.depth), (uint32_t)(img_off * 2), tx0, ty0, kTW, kTH, kTW,
                              a.W, a.H};
@@ -139,15 +139,6 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
 
         // kBatch proposals at a time: all their probes are issued before any is consumed (a far probe is a
         // global round trip; waiting for each one inside its branch made this kernel 10x slower)
-        u64 cmask = 0ull;   // lanes c and C+c hold the mask of this wave's pixels of class c (uniform-node path)
-        if (uniform) {
-            for (int c = 0; c < a.C; ++c) {
-                const u64 m = __ballot(live && label == (uint32_t)c);
-                if (lane == c || lane == a.C + c) cmask = m;
-            }
-        }
-        const int child0 = node0 * 2 - a.node_start;
-
         for (int jb = j0; jb < j1; jb += kBatch) {
             Probe pu[kBatch], pv[kBatch];
             float thr[kBatch];
@@ -175,37 +166,16 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
                 if (j >= j1) break;                              // wave-uniform
                 const float f = zero_depth ? 0.0f : (float)(probe_value(pu[k]) - probe_value(pv[k]));
                 const bool is_left_px = f < thr[k];              // tree_train.cu:57-58
-                if (uniform) {
-                    const u64 left = __ballot(live && is_left_px) & live_mask;
-                    if (lane < 2 * a.C) {
-                        const bool is_left = lane < a.C;
-                        const int c = is_left ? lane : lane - a.C;
-                        const unsigned n = (unsigned)__popcll(cmask & (is_left ? left : ~left));
-                        const int child = child0 + (is_left ? 0 : 1);
-                        if (n) {
-                            if (LDSHIST) atomicAdd(&s_hist[((j - j0) * n_children + child) * a.C + c], n);
-                            else atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + c, (u64)n);
-                        }
-                    }
-                } else if (live) {
-                    const int child = node * 2 + (is_left_px ? 0 : 1) - a.node_start;
-                    if (LDSHIST) atomicAdd(&s_hist[((j - j0) * n_children + child) * a.C + (int)label], 1u);
-                    else atomicAdd(a.counts + ((size_t)j * a.NB + child) * a.C + label, (u64)1);
+                const u64 left = __ballot(live && is_left_px);
+                const u64 part = peers & (is_left_px ? left : ~left);
+                if (live && lane == __ffsll((long long)part) - 1) {
+                    const unsigned n = (unsigned)__popcll(part);
+                    const int bin = bin0 + (is_left_px ? 0 : a.C);
+                    atomicAdd(a.counts + (size_t)j * a.NB * a.C + bin, (u64)n);
                 }
             }
         }
     }
-    if (LDSHIST) {   // one add per non-empty bin per workgroup and pass
-        __syncthreads();
-        for (int i = tid; i < hist_words; i += 256) {
-            const unsigned int v = s_hist[i];
-            if (v) {
-                const int jj = i / (n_children * a.C), rest = i - jj * (n_children * a.C);
-                atomicAdd(a.counts + ((size_t)(j0 + jj) * a.NB) * a.C + rest, (u64)v);
-            }
-        }
-    }
-  }
 }
 
 // ---- gini helpers (tree_train.cu:66-97), fp32 exactly as written ----
@@ -400,25 +370,10 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    // private LDS histogram while pj >= 8 proposals of (children x classes) words fit in 56 KB
-    const long long words_per_proposal = (long long)(node_end - node_start) * n_classes;
-    long long pj = (56 * 1024 / 4) / (words_per_proposal > 0 ? words_per_proposal : 1);
-    if (pj > n_proposals) pj = n_proposals;
-    const char *env = getenv("RDF_TRAIN_LDS_HIST");
-    const bool lds_hist = pj >= 8 && !(env && env[0] == '0');
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (lds_hist) {
-        a.pj = (int)pj;
-        long long grid = (long long)cus * 2;
-        if (grid > n_tiles) grid = n_tiles;
-        hipLaunchKernelGGL(k_train_histogram<true>, dim3((unsigned)grid), dim3(256), (size_t)(pj * words_per_proposal * 4), st, a);
-    } else {
-        a.pj = 0;
-        long long grid = (long long)cus * 8;
-        if (grid > n_tiles) grid = n_tiles;
-        hipLaunchKernelGGL(k_train_histogram<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
-    }
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long grid = (long long)cus * 8;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(k_train_histogram, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--proposals", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=1)
+    ap.add_argument("--noisy-labels", action="store_true", help="per-pixel random classes (no spatial coherence)")
     a = ap.parse_args()
     import torch
     from oracle import train_numpy as tn
@@ -33,6 +34,8 @@ def main():
     for i in range(a.images):
         valid = (depth[i] != 0) & (depth[i] != 65535)
         cls = 1 + ((xx > w // 2).astype(int) + 2 * (depth[i] > 4000).astype(int)) % 3
+        if a.noisy_labels:
+            cls = np.random.default_rng(i).integers(1, C, size=(h, w))
         labels[i][valid] = cls[valid]
     n_lab = int((labels > 0).sum())
     ds = _ArrayDataset(depth, labels, C, per_block=a.images)
