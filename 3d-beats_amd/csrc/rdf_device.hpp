@@ -53,36 +53,38 @@ __device__ __forceinline__ bool fast_divide_ok(float a)   // the verified numera
 // falls inside it (cells outside the image already hold 65535), else by global memory with the
 // per-axis bounds check of cu_utils.hpp:79-86.  The loads are only ISSUED here; their values are
 // consumed after all probes of the level have been issued, so every probe of a level is in flight
-// together and nothing waits inside a divergent branch (an earlier version waited vmcnt(0) per probe).  `depth_b` is the wave-uniform batch base; offsets are 32-bit byte offsets
-// (a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is < 2^24 when used).
+// together and nothing waits inside a divergent branch (an earlier version waited vmcnt(0) per probe).
+// `img_b` is the wave-uniform base of the current image (a scalar register pair, so a far probe's address is
+// one 32-bit byte offset: a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is
+// < 2^24 when used).  tile[-1] must hold 65535: lanes that leave the tile read that cell, so a probe outside
+// the image needs no separate constant.
 struct ProbeCtx {
-    const uint16_t *tile;   // LDS
-    const char *depth_b;
-    uint32_t img_boff;
+    const uint16_t *tile;   // LDS; tile[-1] == 65535
+    const char *img_b;
     int tx0, ty0, tw, th, twp, W, H;
 };
 
 struct Probe {
     uint32_t lds_v, glb_v;   // the two candidate values
-    bool in_tile, inb;
+    bool from_global;
 };
 
 // (cx, cy) = probe position RELATIVE TO THE STAGED TILE (the caller adds the offsets to the pixel's own
 // tile-relative position); image coordinates are only rebuilt for lanes that leave the tile.
 __device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int cx, int cy)
 {
-    Probe p;
-    p.in_tile = (uint32_t)cx < (uint32_t)c.tw && (uint32_t)cy < (uint32_t)c.th;
-    const uint32_t li = p.in_tile ? __umul24((uint32_t)cy, (uint32_t)c.twp) + (uint32_t)cx : 0u;
-    p.lds_v = c.tile[li];
-    p.glb_v = 0u;
-    p.inb = false;
-    if (!p.in_tile) {
+    const bool in_tile = (uint32_t)cx < (uint32_t)c.tw && (uint32_t)cy < (uint32_t)c.th;
+    const int li = in_tile ? (int)(__umul24((uint32_t)cy, (uint32_t)c.twp) + (uint32_t)cx) : -1;
+    uint32_t undefined;
+    asm("" : "=v"(undefined));   // glb_v is only read where from_global is set
+    Probe p = {c.tile[li], undefined, false};
+    if (!in_tile) {
         const int x = add_wrap(cx, c.tx0), y = add_wrap(cy, c.ty0);
-        p.inb = (uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H;
-        if (p.inb) {   // only far lanes touch global memory; the value is consumed after the branch
+        if ((uint32_t)x < (uint32_t)c.W && (uint32_t)y < (uint32_t)c.H) {
+            // only far lanes touch global memory; the value is consumed after the branch
             const uint32_t go = (__umul24((uint32_t)y, (uint32_t)c.W) + (uint32_t)x) << 1;
-            p.glb_v = *reinterpret_cast<const uint16_t *>(c.depth_b + (c.img_boff + go));
+            p.glb_v = *reinterpret_cast<const uint16_t *>(c.img_b + go);
+            p.from_global = true;
         }
     }
     return p;
@@ -90,7 +92,8 @@ __device__ __forceinline__ Probe probe_issue(const ProbeCtx &c, int cx, int cy)
 
 __device__ __forceinline__ int probe_value(const Probe &p)
 {
-    return (int)(p.in_tile ? p.lds_v : (p.inb ? p.glb_v : kNoPixel));
+    const uint32_t g = p.glb_v, l = p.lds_v;
+    return (int)(p.from_global ? g : l);
 }
 
 } // namespace

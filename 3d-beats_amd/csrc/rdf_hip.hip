@@ -47,7 +47,7 @@ constexpr int kGroup = 4;          // trees walked interleaved by one lane
 constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
 constexpr int kDefaultLdsBudget = 40000;   // node table + depth tile per workgroup
 constexpr int kDefaultHalo = 16;   // depth pixels staged around a tile's centres
-constexpr uint32_t kFlagLeft = 1u, kFlagRight = 2u, kFlagExact = 4u;
+constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
 constexpr int kSchedSlots = 256;
 
 // Dynamic tile queue state, one slot per (device, stream) in use: {next tile, workgroups finished}.
@@ -60,7 +60,7 @@ __device__ unsigned int g_sched[kSchedSlots][2];
 //   w0 = int24 floor(s*u.x) | T[7:0]   << 24        T = integer threshold (see thresh_to_int)
 //   w1 = int24 floor(s*u.y) | T[15:8]  << 24
 //   w2 = int24 floor(s*v.x) | (T >> 16) << 24       (signed byte: -1, 0 or 1)
-//   w3 = int24 floor(s*v.y) | flags    << 24        flags: kFlagLeft/Right = that child continues,
+//   w3 = int24 floor(s*v.y) | flags    << 24        flags: kFlagLeftLeaf/RightLeaf = that side is a leaf,
 //                                                          kFlagExact = use the exact record
 // Why integers are enough: for every depth d in [1,65534] and every fp32 a that is +-0 or has a
 // biased exponent in [40,149] (|a| < 2^23), floor(IEEE a/d) == floor(fastdiv(float(floor(a)), d))
@@ -108,10 +108,11 @@ struct EvalArgs {
     float s;
 };
 
-// floor(x) == -1  <=>  -1 <= x < 0   (NaN: false).  tree_eval.cu:101-102 / :186-187.
+// A side continues iff floor(x) == -1  <=>  -1 <= x < 0   (NaN: false); anything else makes it a leaf.
+// tree_eval.cu:101-102 / :186-187.
 __device__ __forceinline__ uint32_t child_flags(float l, float r)
 {
-    return ((l >= -1.0f && l < 0.0f) ? kFlagLeft : 0u) | ((r >= -1.0f && r < 0.0f) ? kFlagRight : 0u);
+    return ((l >= -1.0f && l < 0.0f) ? 0u : kFlagLeftLeaf) | ((r >= -1.0f && r < 0.0f) ? 0u : kFlagRightLeaf);
 }
 
 // Numerators the integer record represents exactly (see NodeRec16): +-0, or biased exponent 40..149.
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             lds_nodes[i] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
         }
     }
+    if (tid == 0) lds_tile[-1] = (uint16_t)kNoPixel;   // what a probe outside the tile reads from LDS (rdf_device.hpp)
     // (made visible by the first tile's barriers)
 
     unsigned long long st_px = 0, st_lv = 0, st_lf = 0;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         const int tx0 = (int)(tx * 64u) * a.r - a.halo;
         const int ty0 = (int)(ty * tile_rows) * a.r - a.halo;
 
-        const ProbeCtx pc = {lds_tile, depth_b, img_boff, tx0, ty0, tw, th, twp, a.W, a.H};
+        const ProbeCtx pc = {lds_tile, depth_b + img_boff, tx0, ty0, tw, th, twp, a.W, a.H};
 
         // ---- empty tile?  (live frames are mostly background.)  Every wave looks at the centre depths of its
         // own rows straight from global memory; a tile without a single pixel to evaluate is not staged.
@@ -425,9 +427,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             const bool walking = (int)h[k] > 0;
                             if (STATS && c0 == 0) st_lv += walking ? 1u : 0u;
                             const uint32_t side = (probe_value(qu[k]) - probe_value(qv[k])) < n[k].t ? 0u : 1u;
-                            const bool cont = ((n[k].flags >> side) & 1u) != 0u;      // kFlagLeft = bit 0, kFlagRight = bit 1
-                            const uint32_t child = h[k] * 2u + side;                   // also (node-1)*2 + side + 2
-                            const uint32_t next = cont ? child : child + (kDone - 2u);
+                            const uint32_t stop = (n[k].flags >> side) & 1u;           // kFlagLeftLeaf = bit 0, kFlagRightLeaf = bit 1
+                            const uint32_t next = ((h[k] << 1) | side) | (stop << 31);  // low bits: (node-1)*2 + side + 2
                             h[k] = walking ? next : h[k];
                         }
                     }
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 #pragma unroll
                     for (int k = 0; k < kGroup; ++k) {
                         if ((int)h[k] < 0 && h[k] != kIdle) {
-                            const uint32_t leaf = h[k] & ~kDone;   // (node - 1) * 2 + side
+                            const uint32_t leaf = (h[k] & ~kDone) - 2u;   // (node - 1) * 2 + side
                             any_leaf = true;
                             if (STATS && c0 == 0) st_lf++;
                             const float *pp = a.forest +
@@ -778,7 +779,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
 
-    // ---- LDS plan: [node table: T*(2^K-1)*16 B][depth tile: th*twp*2 B][queue mailbox 16 B] ----
+    // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B] ----
     const long long budget = lds_budget();
     int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", kDefaultHalo);
     long long tile_bytes = 0;
@@ -794,12 +795,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         }
     }
     int K = 0;
-    while (K < max_depth && (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 16 <= budget) ++K;
+    while (K < max_depth && (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 32 <= budget) ++K;
     a.lds_levels = K;
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
-    a.lds_tile_off = (uint32_t)node_bytes;
-    a.lds_mail_off = (uint32_t)(node_bytes + tile_bytes);
-    const int lds_bytes = (int)(node_bytes + tile_bytes + 16);
+    a.lds_tile_off = (uint32_t)(node_bytes + 16);
+    a.lds_mail_off = (uint32_t)(node_bytes + 16 + tile_bytes);
+    const int lds_bytes = (int)(node_bytes + tile_bytes + 32);
 
     a.sched = sched_slot(stream);
 

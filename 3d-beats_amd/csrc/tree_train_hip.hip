@@ -63,13 +63,15 @@ struct HistArgs {
 // no faster at any level (r01 notes in DESIGN.md).
 __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
 {
-    __shared__ uint16_t s_tile[kTH * kTW];
+    __shared__ uint16_t s_buf[8 + kTH * kTW];
+    uint16_t *s_tile = s_buf + 8;   // s_tile[-1] = 65535: what a probe outside the tile reads (rdf_device.hpp)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t per_img = (uint32_t)a.W * (uint32_t)a.H;
 
     // Are all numerators of all proposals inside the range the shared-reciprocal divide is verified for?  (They
     // are, for anything make_random_features draws.)  Decided once per workgroup: testing 4 numerators per
     // proposal per wave in the loop below made the kernel scalar-ALU bound.
+    if (threadIdx.x == 0) s_buf[7] = (uint16_t)kNoPixel;   // (visible after the barrier below)
     bool mine_ok = true;
     for (int i = tid; i < a.P * 5; i += 256)
         if (i % 5 != 4) mine_ok = mine_ok && fast_divide_ok(a.props[i]);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
         }
         const int bin0 = (node * 2 - a.node_start) * a.C + (int)label;   // left child's bin; right child's is + C
 
-        const ProbeCtx pc = {s_tile, reinterpret_cast<const char *>(a.depth), (uint32_t)(img_off * 2), tx0, ty0, kTW, kTH, kTW,
+        const ProbeCtx pc = {s_tile, reinterpret_cast<const char *>(a.depth) + img_off * 2, tx0, ty0, kTW, kTH, kTW,
                              a.W, a.H};
         const f2 r2 = {rcp, rcp}, nd = {-df, -df};
 
