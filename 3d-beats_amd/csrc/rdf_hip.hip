@@ -45,8 +45,8 @@ namespace {
 
 constexpr int kGroup = 4;          // trees walked interleaved by one lane
 constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
-constexpr int kDefaultLdsBudget = 40000;   // node table + depth tile per workgroup
-constexpr int kDefaultHalo = 16;   // depth pixels staged around a tile's centres
+constexpr int kDefaultLdsBudget = 32000;   // node table + depth tile per workgroup
+constexpr int kDefaultHalo = 24;   // depth pixels staged around a tile's centres
 constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
 constexpr int kSchedSlots = 256;
 
