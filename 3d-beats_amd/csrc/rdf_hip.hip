@@ -9,12 +9,12 @@
 //     4 rows per wave, rows of the waves interleaved) whose depth neighbourhood it stages in LDS;
 //     the label store is one 128-byte line;
 //   * per-tree leaf PDFs are added in registers in tree order (canonical order, no atomics);
-//   * node records are 16 bytes {int24 floor(s*u), int24 floor(s*v), integer threshold, flags}:
+//   * node records are 16 bytes {4 x 23-bit floor(s*u), floor(s*v), integer threshold, flags}, decoded with one convert per numerator:
 //     the top levels of every tree live in LDS, deeper levels are ONE 128-bit load each from the
 //     packed table (rdf_forest_pack) or, for the unpacked entry point, the reference's own
 //     7+2C-float records.  An earlier version with two loads per node was bound by the L1 tag rate
 //     (one cache line per clock per CU, profiles/): what counts is lines touched per wave
-//     instruction, not bytes.  The current version is bound by VALU issue;
+//     instruction, not bytes.  What bounds the current version: DESIGN.md section 4;
 //   * all probes of a level are issued before any is consumed: nothing waits inside a divergent
 //     branch (an earlier version serialised eight global round trips per level that way);
 //   * the workgroup's depth tile plus a halo is staged in LDS (out-of-image cells = 65535), so
@@ -56,18 +56,22 @@ constexpr int kSchedSlots = 256;
 __device__ unsigned int g_sched[kSchedSlots][2];
 
 // ---- node records --------------------------------------------------------------------------
-// Hot record, 16 bytes, one 128-bit load per node:
-//   w0 = int24 floor(s*u.x) | T[7:0]   << 24        T = integer threshold (see thresh_to_int)
-//   w1 = int24 floor(s*u.y) | T[15:8]  << 24
-//   w2 = int24 floor(s*v.x) | (T >> 16) << 24       (signed byte: -1, 0 or 1)
-//   w3 = int24 floor(s*v.y) | flags    << 24        flags: kFlagLeftLeaf/RightLeaf = that side is a leaf,
-//                                                          kFlagExact = use the exact record
-// Why integers are enough: for every depth d in [1,65534] and every fp32 a that is +-0 or has a
-// biased exponent in [40,149] (|a| < 2^23), floor(IEEE a/d) == floor(fastdiv(float(floor(a)), d))
-// -- checked exhaustively on gfx950 by tools/verify_intoffset.hip and tools/verify_fastdiv.hip
-// (1.2e14 and 2.1e14 pairs, 0 mismatches; logs under profiles/).  Any other numerator (huge,
-// denormal, inf, NaN) flags the node kFlagExact and the kernel takes the IEEE divide on the fp32
-// values of the exact record.
+// Hot record, 16 bytes, one 128-bit load per node.  Each word carries a numerator in its high 23 bits, a zero
+// guard bit and one byte of unrelated payload:
+//   w0 = floor(s*u.x) << 9 | T[7:0]         T = integer threshold (see thresh_to_int), 24-bit two's complement
+//   w1 = floor(s*u.y) << 9 | T[15:8]
+//   w2 = floor(s*v.x) << 9 | T[23:16]
+//   w3 = floor(s*v.y) << 9 | flags          flags: kFlagLeftLeaf/RightLeaf = that side is a leaf,
+//                                                  kFlagExact = use the exact record
+// The numerator is decoded with ONE instruction, v_cvt_f32_i32 of the whole word = 512*(x + e), 0 <= e <= 1/2: the
+// payload only adds a fraction of a unit, floor((x+e)/d) = floor(x/d) for integers, and the divide works on
+// 512*d (exact scalings of the verified sequence).
+// Why this is enough: for every depth d in [1,65535] and every fp32 a that is +-0 or has a biased exponent in
+// [40,148] (|a| < 2^22), floor(IEEE a/d) == floor(fastdiv(cvt(floor(a) << 9 | p), 512 d)) for every payload p
+// -- checked exhaustively on gfx950 by tools/verify_intoffset.hip, tools/verify_fastdiv.hip and
+// tools/verify_payload.hip (1.2e14, 2.1e14 and 1.4e14 cases, 0 mismatches; logs under profiles/).  Any other
+// numerator (huge, denormal, inf, NaN) flags the node kFlagExact and the kernel takes the IEEE divide on the
+// fp32 values of the exact record.
 struct alignas(16) NodeRec16 {
     uint32_t w[4];
 };
@@ -115,11 +119,11 @@ __device__ __forceinline__ uint32_t child_flags(float l, float r)
     return ((l >= -1.0f && l < 0.0f) ? 0u : kFlagLeftLeaf) | ((r >= -1.0f && r < 0.0f) ? 0u : kFlagRightLeaf);
 }
 
-// Numerators the integer record represents exactly (see NodeRec16): +-0, or biased exponent 40..149.
+// Numerators the integer record represents exactly (see NodeRec16): +-0, or biased exponent 40..148.
 __device__ __forceinline__ bool int_offset_ok(float a)
 {
     const uint32_t b = __float_as_uint(a);
-    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 109u;
+    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 108u;
 }
 
 // f = depth[u] - depth[v] is an integer in [-65535, 65535], so `f < thresh` (tree_eval.cu:107)
@@ -145,10 +149,10 @@ __device__ __forceinline__ NodeRec16 encode_node(float sux, float suy, float svx
     }
     const uint32_t t = (uint32_t)thresh_to_int(thresh);   // two's complement, |T| <= 65536
     NodeRec16 r;
-    r.w[0] = ((uint32_t)nx & 0xFFFFFFu) | ((t & 0xFFu) << 24);
-    r.w[1] = ((uint32_t)ny & 0xFFFFFFu) | (((t >> 8) & 0xFFu) << 24);
-    r.w[2] = ((uint32_t)mx & 0xFFFFFFu) | (((t >> 16) & 0xFFu) << 24);
-    r.w[3] = ((uint32_t)my & 0xFFFFFFu) | (flags << 24);
+    r.w[0] = ((uint32_t)nx << 9) | (t & 0xFFu);
+    r.w[1] = ((uint32_t)ny << 9) | ((t >> 8) & 0xFFu);
+    r.w[2] = ((uint32_t)mx << 9) | ((t >> 16) & 0xFFu);
+    r.w[3] = ((uint32_t)my << 9) | flags;
     return r;
 }
 
@@ -157,24 +161,27 @@ __device__ __forceinline__ uint4 select4(bool c, const uint4 a, const uint4 b)
     return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 
+constexpr float kNumScale = 512.0f;   // a decoded numerator is 512 * (x + e), see NodeRec16
+
 struct Node {
-    float ax, ay, bx, by;   // numerators of the u and v offsets (integers on the fast path)
+    float ax, ay, bx, by;   // numerators of the u and v offsets: kNumScale * (integer + e) from a hot record,
+                            // the fp32 values s*u, s*v themselves on a kFlagExact node
     int t;                  // integer threshold
-    uint32_t flags;
+    uint32_t flags;         // low 3 bits; the bits above are not defined
 };
 
 __device__ __forceinline__ Node decode_node(const uint4 w)
 {
     Node n;
-    n.ax = (float)((int)(w.x << 8) >> 8);
-    n.ay = (float)((int)(w.y << 8) >> 8);
-    n.bx = (float)((int)(w.z << 8) >> 8);
-    n.by = (float)((int)(w.w << 8) >> 8);
-    // T = {w0.b3, w1.b3, w2.b3, sign(w2.b3)} in two byte permutes (v_perm_b32: selectors 0-3 pick bytes of the
-    // second operand, 4-7 of the first, 11 replicates the sign of the first operand's top byte, 12 is 0x00)
-    const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0703u);
-    n.t = (int)__builtin_amdgcn_perm(w.z, lo, 0x0b070100u);
-    n.flags = w.w >> 24;
+    n.ax = (float)(int)w.x;
+    n.ay = (float)(int)w.y;
+    n.bx = (float)(int)w.z;
+    n.by = (float)(int)w.w;
+    // T = {w0.b0, w1.b0, w2.b0} in two byte permutes (v_perm_b32: selectors 0-3 pick bytes of the second
+    // operand, 4-7 of the first, 12 is 0x00), then sign-extended from 24 bits
+    const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0400u);
+    n.t = (int)(__builtin_amdgcn_perm(w.z, lo, 0x0c040100u) << 8) >> 8;
+    n.flags = w.w;
     return n;
 }
 
@@ -305,8 +312,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             // refined reciprocal shared by every divide of this pixel (fast path only)
             const float r0 = __builtin_amdgcn_rcpf(df);
             const float rcp = __builtin_fmaf(__builtin_fmaf(-df, r0, 1.0f), r0, r0);
-            const f2 rcp2 = {rcp, rcp};
-            const f2 ndf2 = {-df, -df};
+            const float rcp_s = rcp * (1.0f / kNumScale), df_s = df * kNumScale;   // exact scalings
+            const f2 rcp2 = {rcp_s, rcp_s};
+            const f2 ndf2 = {-df_s, -df_s};
 
             float best = 0.0f;
             int best_c = 0;
@@ -389,10 +397,12 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             }
 #pragma unroll
                             for (int k = 0; k < kGroup; ++k) {
-                                ux[k] = add_wrap(xl, floor_i32(n[k].ax / df));
-                                uy[k] = add_wrap(yl, floor_i32(n[k].ay / df));
-                                vx[k] = add_wrap(xl, floor_i32(n[k].bx / df));
-                                vy[k] = add_wrap(yl, floor_i32(n[k].by / df));
+                                // lanes on an ordinary node still hold kNumScale * (x + e): same floor (NodeRec16)
+                                const float den = (n[k].flags & kFlagExact) ? df : df_s;
+                                ux[k] = add_wrap(xl, floor_i32(n[k].ax / den));
+                                uy[k] = add_wrap(yl, floor_i32(n[k].ay / den));
+                                vx[k] = add_wrap(xl, floor_i32(n[k].bx / den));
+                                vy[k] = add_wrap(yl, floor_i32(n[k].by / den));
                             }
                         } else {
                             // q0 = a*rcp; rem = a - d*q0 (exact, fma); q = q0 + rem*rcp.  Packed f32 math,
@@ -515,8 +525,8 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     n.sux = s * p[0]; n.suy = s * p[1]; n.svx = s * p[2]; n.svy = s * p[3];
     n.thresh = p[4];
     NodeRec16 h16 = encode_node(n.sux, n.suy, n.svx, n.svy, p[4], p[5], p[6]);
-    if (force_exact) h16.w[3] |= kFlagExact << 24;   // test knob: exercise the IEEE branch everywhere
-    n.flags = h16.w[3] >> 24;
+    if (force_exact) h16.w[3] |= kFlagExact;   // test knob: exercise the IEEE branch everywhere
+    n.flags = h16.w[3] & 0xFFu;
     n.pad0 = n.pad1 = 0;
     packed16[slot] = h16;
     packed32[slot] = n;

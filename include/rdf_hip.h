@@ -91,8 +91,8 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers,
                     int labels_reduce, float scale_factor, void *stream);
 
 /*
- * Load-time repack of a forest into a table of 16-byte hot records {int24 floor(s*u), int24
- * floor(s*v), integer threshold, child flags} followed by a table of 32-byte exact records
+ * Load-time repack of a forest into a table of 16-byte hot records {23-bit floor(s*u), 23-bit
+ * floor(s*v), integer threshold, leaf flags} followed by a table of 32-byte exact records
  * (fp32 s*u, s*v) that is read only for nodes whose numerators the integer form cannot
  * represent.  The reference has no counterpart: its "load" is the plain upload at
  * src/decision_tree.py:148-158.  The packed tables depend on scale_factor and must be rebuilt

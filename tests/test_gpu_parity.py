@@ -188,13 +188,15 @@ ADVERSARIAL = [8388607.5, 8388607.0, 8388608.0, -8388608.0, -8388608.5, -8388607
                -1e-30, 1e-45, -1e-45, 2.0 ** -87, -(2.0 ** -87), 2.0 ** -88, 11.999999, -11.999999, 23.999998,
                0.99999994, -0.99999994, -1.0000001, 65534.0, 65533.996, 131067.99, 4000.0, 3999.9998, -4000.0,
                0.0, -0.0, 0.5, -0.5, 1e38, -1e38, float("inf"), float("-inf"), float("nan"), 2.5e6, -2.5e6,
-               7999.9995, 12345.678, -12345.678, 1.17549435e-38, 8388606.5]
+               7999.9995, 12345.678, -12345.678, 1.17549435e-38, 8388606.5,
+               # edges of the 23-bit numerator field of the hot record (|a| < 2^22 stays on the fast path)
+               4194303.5, 4194303.75, 4194304.0, -4194304.0, -4194303.5, -4194304.5, 4194302.0, -4194303.0, 2097151.9]
 
 
 @pytest.mark.parametrize("path", ["packed", "direct"])
 @pytest.mark.parametrize("force_exact", [0, 1])
 def test_adversarial_numerators_and_exact_fallback(path, force_exact, rdf, gpu_runtime, oracle):
-    """Offsets at the edges of what the 16-byte integer record can hold (|a| >= 2^23, denormals, inf, NaN,
+    """Offsets at the edges of what the 16-byte integer record can hold (|a| >= 2^22, denormals, inf, NaN,
     values a hair below integers) must take the IEEE branch and still match; force_exact=1 sends EVERY
     node of the packed path through that branch."""
     rng = np.random.default_rng(77)
