@@ -27,9 +27,15 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr int kHalo = 16;
-constexpr int kTW = 64 + 2 * kHalo;          // staged tile: 96 columns
-constexpr int kRows = 4;                      // one label row per wave, 4 waves
-constexpr int kTH = kRows + 2 * kHalo;        // 36 rows
+// A wave covers a kBW x kBH block of pixels rather than a 64 x 1 row segment: pixels of the same (node, class) are
+// compact in 2-D, so a block holds fewer distinct groups -- and issues fewer atomics -- than a strip.  The
+// workgroup's 4 waves sit side by side.
+constexpr int kBW = 8, kBH = 8;
+static_assert(kBW * kBH == 64, "one pixel per lane");
+constexpr int kCols = 4 * kBW;                // pixels per tile row
+constexpr int kRows = kBH;
+constexpr int kTW = kCols + 2 * kHalo;        // staged tile columns
+constexpr int kTH = kRows + 2 * kHalo;        // staged tile rows
 constexpr int kMaxClasses = 64;
 constexpr int kBatch = 4;                     // proposals evaluated together: 8 probes in flight per lane
 
@@ -82,8 +88,8 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
         const uint32_t per = a.tiles_x * a.tiles_y;
         const uint32_t img = tile / per, rem = tile - img * per;
         const uint32_t ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-        const int x = (int)(tx * 64u) + lane, y = (int)(ty * kRows) + wave;
-        const int tx0 = (int)(tx * 64u) - kHalo, ty0 = (int)(ty * kRows) - kHalo;
+        const int x = (int)(tx * kCols) + wave * kBW + (lane % kBW), y = (int)(ty * kRows) + lane / kBW;
+        const int tx0 = (int)(tx * kCols) - kHalo, ty0 = (int)(ty * kRows) - kHalo;
         const size_t img_off = (size_t)img * per_img;
 
         // does this tile hold any pixel that counts?  (most of a frame is unlabelled background)
@@ -366,7 +372,7 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
     a.depth = depth; a.labels = labels; a.nodes = nodes_by_pixel; a.props = proposals; a.counts = counts;
     a.W = dim_x; a.H = dim_y; a.P = n_proposals; a.C = n_classes; a.NB = nodes_per_block;
     a.node_start = node_start; a.node_end = node_end;
-    a.tiles_x = (uint32_t)(dim_x + 63) / 64u;
+    a.tiles_x = (uint32_t)(dim_x + kCols - 1) / kCols;
     a.tiles_y = (uint32_t)(dim_y + kRows - 1) / kRows;
     const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
