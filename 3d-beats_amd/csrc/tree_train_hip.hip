@@ -6,9 +6,8 @@
 //   * the histogram kernel keeps one PIXEL per lane and loops over the proposals (wave-uniform, read
 //     through the scalar cache) with the pixel's depth neighbourhood staged in LDS, where the
 //     reference spends one thread and one 64-bit global atomic per (pixel, proposal);
-//   * when the pixels of a wave sit in the same node -- the rule on the upper levels -- the wave
-//     counts with ballots and popcounts and issues at most 2*C atomics per proposal, from distinct
-//     lanes to distinct bins; only mixed waves fall back to one atomic per lane;
+//   * a wave covers an 8x8 block of pixels and counts with ballots and popcounts: one atomic per
+//     (node, class, side) the block touches per proposal instead of one per pixel;
 //   * the next level's node list is built by an ordered scan (the reference appends with an atomic
 //     counter, i.e. in scheduler order), so the whole training run is reproducible bit for bit;
 //   * floor((u)/d) uses the shared-reciprocal divide verified exhaustively for inference

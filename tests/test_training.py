@@ -92,14 +92,24 @@ def test_device_trainer_matches_restatement_bit_for_bit(cfg, rdf, gpu_runtime):
     assert np.array_equal(tree.tree_out_cu.get().view(np.uint32), got.view(np.uint32))
 
 
-def test_proposal_generator_matches_restatement(rdf):
+@pytest.mark.parametrize("seed,n", [(123, 9), (0, 1), (7, 2000), (20211003, 257)])
+def test_proposal_generator_matches_restatement(seed, n, rdf):
+    """The bulk generator (11 raw MT19937 outputs per proposal) must give the restatement's per-draw proposals
+    bit for bit AND leave the global RNG in the same state, so that later draws stay aligned too."""
     dt = importlib.import_module("3d-beats_amd.decision_tree")
-    np.random.seed(123)
-    a = np.zeros((9, 5), np.float32)
-    dt.make_random_features(9, a)
-    np.random.seed(123)
-    b = tn.make_random_features(9)
+    np.random.seed(seed)
+    a = np.zeros((n, 5), np.float32)
+    dt.make_random_features(n, a)
+    state_a = np.random.get_state()
+    np.random.seed(seed)
+    b = tn.make_random_features(n)
+    state_b = np.random.get_state()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(state_a[1], state_b[1]) and state_a[2:] == state_b[2:]
+    np.random.seed(seed)
+    c = np.zeros((n, 5), np.float32)
+    dt.make_random_features_loop(n, c)
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
 
 
 @pytest.mark.gpu
