@@ -39,6 +39,10 @@ SIGNATURES = {
     "rdf_train_init": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_train_histogram": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
                                      _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "rdf_train_histogram_left": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
+                                          _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "rdf_train_right_counts": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
+                                        _c_void_p]),
     "rdf_train_pick_best": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_train_next_active": (_c_int, [_c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),

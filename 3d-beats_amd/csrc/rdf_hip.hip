@@ -35,6 +35,7 @@
 #include <string.h>
 
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <utility>
 
@@ -662,17 +663,19 @@ unsigned int *sched_slot(void *stream)
 struct LaunchGeom {
     int blocks_per_cu;
 };
-std::map<std::pair<const void *, int>, int> g_occ_cache;
+std::map<std::tuple<int, const void *, int>, int> g_occ_cache;   // (device, kernel, LDS bytes) -> workgroups per CU
 
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
 int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
     auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, FULLROWS>;
     const void *kp = reinterpret_cast<const void *>(kern);
-    int per_cu = 0;
+    int per_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    const auto key = std::make_tuple(dev, kp, lds_bytes);   // the function attribute below is per device
     {
         std::lock_guard<std::mutex> lock(g_sched_mu);
-        auto it = g_occ_cache.find({kp, lds_bytes});
+        auto it = g_occ_cache.find(key);
         if (it != g_occ_cache.end()) per_cu = it->second;
     }
     if (per_cu == 0) {
@@ -685,7 +688,7 @@ int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
             n = 1;
         per_cu = n;
         std::lock_guard<std::mutex> lock(g_sched_mu);
-        g_occ_cache[{kp, lds_bytes}] = per_cu;
+        g_occ_cache[key] = per_cu;
     }
     // persistent workgroups: as many as are resident at once, never more than there are tiles
     long long grid = (long long)cus * per_cu;

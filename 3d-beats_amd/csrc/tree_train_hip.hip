@@ -60,6 +60,7 @@ struct HistArgs {
     u64 *counts;          // [P][NB][C]
     uint32_t n_tiles, tiles_x, tiles_y;
     int W, H, P, C, NB, node_start, node_end;
+    int left_only;   // count the left children only (the right ones follow from the parents, k_train_right_counts)
 };
 
 // evaluate_random_features (tree_train.cu:4-64).
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
                 const bool is_left_px = f < thr[k];              // tree_train.cu:57-58
                 const u64 left = __ballot(live && is_left_px);
                 const u64 part = peers & (is_left_px ? left : ~left);
-                if (live && lane == __ffsll((long long)part) - 1) {
+                if (live && lane == __ffsll((long long)part) - 1 && (is_left_px || !a.left_only)) {
                     const unsigned n = (unsigned)__popcll(part);
                     const int bin = bin0 + (is_left_px ? 0 : a.C);
                     atomicAdd(a.counts + (size_t)j * a.NB * a.C + bin, (u64)n);
@@ -183,6 +184,22 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
             }
         }
     }
+}
+
+// Right-child counts from the parents: every live pixel of a node goes either left or right, so
+// counts[j][right][c] = parent_counts[node][c] - counts[j][left][c].  Counting only the left side halves the
+// atomics of the histogram kernel, which is what bounds it.  Valid once ALL images have been counted.
+__global__ __launch_bounds__(256) void k_train_right_counts(int n_active, const int32_t *active, int P, int NB, int node_start,
+                                                            int node_end, int C, const u64 *parent_counts, u64 *counts)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n_active * P) return;
+    const int j = (int)(t / n_active), i = (int)(t - (long long)j * n_active);   // neighbouring lanes: neighbouring nodes
+    const int parent = active[i];
+    const int l_child = parent * 2, r_child = parent * 2 + 1;
+    if (l_child < node_start || r_child >= node_end) return;
+    u64 *l = counts + ((size_t)j * NB + (l_child - node_start)) * C;
+    for (int c = 0; c < C; ++c) l[C + c] = parent_counts[(size_t)parent * C + c] - l[c];
 }
 
 // ---- gini helpers (tree_train.cu:66-97), fp32 exactly as written ----
@@ -357,9 +374,9 @@ int rdf_train_init(const uint16_t *labels, size_t n_px, int n_classes, int32_t *
     return (int)hipGetLastError();
 }
 
-int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
-                        int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
-                        int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
+static int train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                           int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes, int node_start,
+                           int node_end, int nodes_per_block, unsigned long long *counts, int left_only, void *stream)
 {
     if (n_img < 0 || dim_x < 0 || dim_y < 0 || n_proposals < 0 || n_classes < 1 || n_classes > kMaxClasses ||
         nodes_per_block < 1 || node_end - node_start > nodes_per_block || node_start < 0)
@@ -371,6 +388,7 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
     a.depth = depth; a.labels = labels; a.nodes = nodes_by_pixel; a.props = proposals; a.counts = counts;
     a.W = dim_x; a.H = dim_y; a.P = n_proposals; a.C = n_classes; a.NB = nodes_per_block;
     a.node_start = node_start; a.node_end = node_end;
+    a.left_only = left_only;
     a.tiles_x = (uint32_t)(dim_x + kCols - 1) / kCols;
     a.tiles_y = (uint32_t)(dim_y + kRows - 1) / kRows;
     const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
@@ -381,6 +399,39 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
     long long grid = (long long)cus * 8;
     if (grid > n_tiles) grid = n_tiles;
     hipLaunchKernelGGL(k_train_histogram, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                        int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
+                        int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
+{
+    return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
+                           node_start, node_end, nodes_per_block, counts, 0, stream);
+}
+
+int rdf_train_histogram_left(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                             int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
+                             int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
+{
+    return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
+                           node_start, node_end, nodes_per_block, counts, 1, stream);
+}
+
+int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,
+                           int node_start, int node_end, int n_classes, const unsigned long long *parent_counts,
+                           unsigned long long *counts, void *stream)
+{
+    if (n_active < 0 || n_proposals < 0 || n_classes < 1 || n_classes > kMaxClasses || nodes_per_block < 1 ||
+        node_end - node_start > nodes_per_block || node_start < 0)
+        return RDF_ERR_BAD_ARG;
+    if (n_active == 0 || n_proposals == 0) return RDF_OK;
+    if (!active_nodes || !parent_counts || !counts) return RDF_ERR_NULL_PTR;
+    const long long n = (long long)n_active * n_proposals;
+    if (n >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(k_train_right_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), n_active, active_nodes, n_proposals, nodes_per_block,
+                       node_start, node_end, n_classes, parent_counts, counts);
     return (int)hipGetLastError();
 }
 

@@ -428,11 +428,17 @@ class DecisionTreeTrainer:
 
                 for node_block_start, node_block_end in node_blocks:
                     self.current_next_node_counts_by_feature_cu_block.fill(0)
-                    chk(lib.rdf_train_histogram(self.depth_cu.ptr, self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr,
-                                                n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
-                                                node_block_start, node_block_end, NB,
-                                                self.current_next_node_counts_by_feature_cu_block.ptr, st()),
-                        "rdf_train_histogram")
+                    # evaluate_random_features, as two calls: the kernel counts the left children, the right ones
+                    # follow from the parents' counts (the whole training set is counted in this one call)
+                    chk(lib.rdf_train_histogram_left(self.depth_cu.ptr, self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr,
+                                                     n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
+                                                     node_block_start, node_block_end, NB,
+                                                     self.current_next_node_counts_by_feature_cu_block.ptr, st()),
+                        "rdf_train_histogram_left")
+                    chk(lib.rdf_train_right_counts(num_active_nodes, self.active_nodes_cu.ptr, P, NB, node_block_start,
+                                                   node_block_end, C, self.node_counts_cu.ptr,
+                                                   self.current_next_node_counts_by_feature_cu_block.ptr, st()),
+                        "rdf_train_right_counts")
                     chk(lib.rdf_train_pick_best(num_active_nodes, self.active_nodes_cu.ptr, P, D, NB, node_block_start,
                                                 node_block_end, C, current_level, self.node_counts_cu.ptr,
                                                 self.current_next_node_counts_by_feature_cu_block.ptr,

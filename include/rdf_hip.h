@@ -175,6 +175,10 @@ int rdf_make_rgba_from_labels(int dim_x, int dim_y, int num_colors, const uint16
  * rdf_train_histogram       evaluate_random_features, tree_train.cu:4-64: counts[j][child - node_start][label] += 1 for
  *                           every live pixel whose children fall in [node_start, node_end); counts is uint64
  *                           [n_proposals][nodes_per_block][n_classes], zeroed by the caller; proposals float32 [P][5]
+ * rdf_train_histogram_left  the same, but only the LEFT children are counted (half the atomics, which bound the kernel);
+ * rdf_train_right_counts    then fills counts[j][right][c] = parent_counts[node][c] - counts[j][left][c] for the children of
+ *                           the active nodes that fall in [node_start, node_end).  Call it once, after every image has
+ *                           been counted; the pair leaves `counts` exactly as rdf_train_histogram does
  * rdf_train_pick_best       pick_best_features, tree_train.cu:99-236 (same arguments)
  * rdf_train_next_active     get_active_nodes_next_level, tree_train.cu:238-273, but in ascending order of the parents
  *                           (the reference appends in scheduler order); *n_next_active is written on the device
@@ -186,6 +190,12 @@ int rdf_train_init(const uint16_t *labels, size_t n_px, int n_classes, int32_t *
 int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
                         int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
                         int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream);
+int rdf_train_histogram_left(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                             int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
+                             int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream);
+int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,
+                           int node_start, int node_end, int n_classes, const unsigned long long *parent_counts,
+                           unsigned long long *counts, void *stream);
 int rdf_train_pick_best(int n_active, const int32_t *active_nodes, int n_proposals, int max_depth, int nodes_per_block,
                         int node_start, int node_end, int n_classes, int level,
                         const unsigned long long *parent_counts, const unsigned long long *counts_by_feature,

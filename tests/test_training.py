@@ -92,6 +92,54 @@ def test_device_trainer_matches_restatement_bit_for_bit(cfg, rdf, gpu_runtime):
     assert np.array_equal(tree.tree_out_cu.get().view(np.uint32), got.view(np.uint32))
 
 
+@pytest.mark.gpu
+def test_left_only_histogram_plus_right_counts_equals_full_histogram(rdf, gpu_runtime):
+    """rdf_train_histogram_left + rdf_train_right_counts must leave the count array exactly as the one-call
+    rdf_train_histogram (= evaluate_random_features) does, here on the last level of a trained tree (many nodes)."""
+    dt = importlib.import_module("3d-beats_amd.decision_tree")
+    depth, labels = make_data(rdf, n=6)
+    C, D, P = 4, 6, 24
+    ds = _ArrayDataset(depth, labels, C, per_block=6)
+    trainer = rdf.DecisionTreeTrainer(6, P)
+    trainer.allocate(ds, P, D)
+    tree = rdf.DecisionTree(D, C)
+    np.random.seed(11)
+    trainer.train(ds, tree)
+    lib, st = gpu_runtime.lib, gpu_runtime.stream
+    # state left behind by train(): nodes_by_pixel / active nodes / node counts of level D-1
+    active = trainer.active_nodes_cu.get()
+    counts_parent = trainer.node_counts_cu.get().reshape(-1, C)
+    nodes_px = trainer.nodes_by_pixel_cu.get()
+    live_nodes = np.unique(nodes_px[nodes_px >= 0])
+    assert live_nodes.size > 4
+    n_act = live_nodes.size
+    assert np.array_equal(np.sort(active[:n_act]), live_nodes)
+    props = np.zeros((P, 5), np.float32)
+    np.random.seed(5)
+    dt.make_random_features(P, props)
+    d_props = rdf.to_device(props)
+    NB = trainer.nodes_per_block
+    n_img, h, w = depth.shape
+    start, end = 0, 1 << D
+    assert end - start <= NB
+    full = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
+    split = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
+    args = (trainer.depth_cu.ptr, trainer.labels_cu.ptr, trainer.nodes_by_pixel_cu.ptr, n_img, w, h, d_props.ptr, P, C,
+            start, end, NB)
+    assert lib.rdf_train_histogram(*args, full.ptr, st()) == 0
+    assert lib.rdf_train_histogram_left(*args, split.ptr, st()) == 0
+    left_only = split.get()
+    assert lib.rdf_train_right_counts(n_act, trainer.active_nodes_cu.ptr, P, NB, start, end, C, trainer.node_counts_cu.ptr,
+                                      split.ptr, st()) == 0
+    want, got = full.get(), split.get()
+    assert want.sum() == P * (nodes_px >= 0).sum()
+    assert (left_only[:, 1::2, :] == 0).all() and left_only.sum() < want.sum()
+    assert np.array_equal(got, want)
+    # parents' counts are what the children add up to
+    for node in live_nodes[:5]:
+        assert np.array_equal(want[0, 2 * node] + want[0, 2 * node + 1], counts_parent[node])
+
+
 @pytest.mark.parametrize("seed,n", [(123, 9), (0, 1), (7, 2000), (20211003, 257)])
 def test_proposal_generator_matches_restatement(seed, n, rdf):
     """The bulk generator (11 raw MT19937 outputs per proposal) must give the restatement's per-draw proposals
