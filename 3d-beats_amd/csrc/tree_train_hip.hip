@@ -234,15 +234,18 @@ __device__ __forceinline__ int count_above_cutoff(const u64 *c, int C, u64 sum, 
     return -1;
 }
 
-// pick_best_features (tree_train.cu:99-236): one lane per active node
+// pick_best_features (tree_train.cu:99-236): one WAVE per active node.  The reference scans the proposals in order
+// and keeps the first one that attains the largest gain (strict >, starting from -1 with proposal 0); here lane l
+// scans proposals l, l+64, ... the same way and the wave then keeps the largest gain, the lowest proposal index
+// among equals -- the same winner.  Lane 0 writes the node.
 __global__ __launch_bounds__(256) void k_train_pick_best(int n_active, const int32_t *active, int P, int D, int NB,
                                                          int node_start, int node_end, int C, int level,
                                                          const u64 *parent_counts, const u64 *by_feature,
                                                          const float *props, float *tree, u64 *child_counts,
                                                          float *best_gain)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_active) return;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= n_active) return;                       // wave-uniform
     const int E = 7 + 2 * C;
     const int parent = active[i];
     const int lchild = parent * 2, rchild = parent * 2 + 1;
@@ -253,13 +256,19 @@ __global__ __launch_bounds__(256) void k_train_pick_best(int n_active, const int
 
     float best_g = -1.f;
     int best_j = 0;
-    for (int j = 0; j < P; ++j) {
+    for (int j = lane; j < P; j += 64) {
         const u64 *lc = by_feature + ((size_t)j * NB + (lchild - node_start)) * C;
         const u64 *rc = by_feature + ((size_t)j * NB + (rchild - node_start)) * C;
         const u64 ls = counts_sum(lc, C), rs = counts_sum(rc, C);
         const float g = (!ls || !rs) ? 0.f : gini_gain(pc, lc, rc, C);
         if (g > best_g) { best_g = g; best_j = j; }
     }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float og = __shfl_xor(best_g, o);
+        const int oj = __shfl_xor(best_j, o);
+        if (og > best_g || (og == best_g && oj < best_j)) { best_g = og; best_j = oj; }
+    }
+    if (lane != 0) return;
     if (!(best_g > prev)) return;
     best_gain[i] = best_g;
 
@@ -447,7 +456,7 @@ int rdf_train_pick_best(int n_active, const int32_t *active_nodes, int n_proposa
     if (n_active == 0 || n_proposals == 0) return RDF_OK;
     if (!active_nodes || !parent_counts || !counts_by_feature || !proposals || !tree_out || !child_counts || !best_gain_per_node)
         return RDF_ERR_NULL_PTR;
-    hipLaunchKernelGGL(k_train_pick_best, dim3((n_active + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(k_train_pick_best, dim3((n_active + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        n_active, active_nodes, n_proposals, max_depth, nodes_per_block, node_start, node_end, n_classes, level,
                        parent_counts, counts_by_feature, proposals, tree_out, child_counts, best_gain_per_node);
     return (int)hipGetLastError();
