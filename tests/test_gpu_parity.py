@@ -407,3 +407,40 @@ def test_two_streams_do_not_share_queue_state(rdf, evs, oracle, gpu_runtime):
             ev.get_labels_forest(Fb, Db, Lb)
     torch.cuda.synchronize()
     assert np.array_equal(La.get(), wa) and np.array_equal(Lb.get(), wb)
+
+
+def test_largest_batch_one_call_addresses(rdf, evs, oracle):
+    """The C ABI addresses a batch with 32-bit pixel offsets (n_img*W*H < 2^31).  Run it at that limit: 5275
+    frames of 848x480 = 2 147 136 000 pixels (4.3 GB of depth, 4.3 GB of labels), a small forest, and check the
+    first, a middle and the last frames against the oracle -- an offset that wrapped would show there."""
+    import torch
+    n, h, w = 5275, 480, 848
+    assert n * h * w < 2 ** 31 <= (n + 1) * h * w
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip("needs 24 GB of free HBM")
+    forest = rdf.synth.forest(3, 5, 4, "trained", first_tree=90)
+    depth = rdf.DeviceArray((n, h, w), np.uint16)
+    # every frame = one of 7 synthetic frames, rolled by a frame-dependent amount: cheap to rebuild on the host
+    base = rdf.synth.frames(["dense", "live", "dense", "live", "live", "dense", "live"], 300, h, w)
+    base_t = torch.from_numpy(base.view(np.int16)).cuda()
+    d_t = depth.torch_bytes().view(torch.int16).view(n, h, w)
+    for i in range(n):
+        d_t[i] = torch.roll(base_t[i % 7], shifts=(i * 13) % w, dims=1)
+    depth.mark_dirty()
+    labels = rdf.DeviceArray((n, h, w), np.uint16).fill(65535)
+    f = rdf.DecisionForest.from_numpy(forest)
+    evs["packed"].get_labels_forest(f, depth, labels)
+    for i in (0, 1, 2637, n - 2, n - 1):
+        host = np.roll(base[i % 7], (i * 13) % w, axis=1)[None]
+        want = np.full((1, h, w), 65535, np.uint16)
+        oracle.eval_forest(host, forest, want)
+        got = labels[i:i + 1].get()
+        assert np.array_equal(got, want), f"frame {i}: {(got != want).sum()} pixels differ"
+    # nothing was written past the batch's own frames: every frame's untouched pixels are still the pre-fill
+    l_t = labels.torch_bytes().view(torch.int16).view(n, h, w)
+    invalid = (d_t == 0) | (d_t == -1)
+    assert not bool(torch.logical_and(l_t != -1, invalid).any())
+    assert not bool(torch.logical_and(l_t == -1, ~invalid).any())   # and every valid pixel did get a label
+    del depth, labels, d_t, l_t, invalid
+    torch.cuda.empty_cache()
