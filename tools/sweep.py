@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--unpacked", action="store_true")
     ap.add_argument("--kinds", default="mixed", choices=["mixed", "interleaved", "dense", "live"])
     ap.add_argument("--reduce", type=int, default=1)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=848)
     ap.add_argument("combos", nargs="*", default=["1024:81920", "512:81920", "512:32768", "256:32768", "256:16384"])
     a = ap.parse_args()
     import torch
@@ -33,7 +35,8 @@ def main():
     forest = rdf.DecisionForest.from_numpy(rdf.synth.forest(a.trees, a.depth, 4, a.topology))
     kinds = {"mixed": None, "interleaved": ["dense", "live"] * (a.frames // 2) + ["dense"] * (a.frames % 2),
              "dense": ["dense"] * a.frames, "live": ["live"] * a.frames}[a.kinds]
-    host = rdf.synth.mixed_batch(a.frames) if kinds is None else rdf.synth.frames(kinds)
+    host = (rdf.synth.mixed_batch(a.frames, 0, a.height, a.width) if kinds is None
+            else rdf.synth.frames(kinds, 0, a.height, a.width))
     depth = rdf.to_device(host)
     red = a.reduce
     labels = rdf.DeviceArray((host.shape[0], host.shape[1] // red, host.shape[2] // red), np.uint16).fill(65535)
@@ -59,7 +62,7 @@ def main():
                 got = labels.get()
                 ref = got if ref is None else ref
                 assert np.array_equal(got, ref), c
-    npx = a.frames * 480 * 848
+    npx = a.frames * a.height * a.width
     for c in combos:
         v = np.array(res[c])
         print(f"block {c[0]:5d} lds {c[1]:7d} rpw {c[2] if len(c) > 2 else 0} halo {c[3] if len(c) > 3 else -1:3d}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
