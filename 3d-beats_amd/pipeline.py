@@ -1,0 +1,114 @@
+"""The per-hand, per-frame chain of the reference's app, on one stream with no host round trip until the result.
+
+Mirror of `App_3d_bz.run_per_hand_pipeline` (/root/reference/src/3d_bz.py:388-522):
+    stencil the depth frame by hand group -> (flip x for the left hand) -> 0 -> 65535 ->
+    LayeredDecisionForest.run -> (flip the labels back) -> RGBA debug image -> mean-shift modes ->
+    fingertip heights above the calibrated plane.
+Every step is a row of SURVEY 8 that this package already has (8a K, 8f-1, 8f-2); this class only owns the
+intermediate buffers and the order.  The reference synchronises the context and reads the label means and the
+depth frame back to the host for the last step (3d_bz.py:461-465, 503-522); here the means and the heights stay
+on the device and ONE small copy (means + heights) ends the frame.
+"""
+import numpy as np
+
+from . import _lib
+from .cuda.mean_shift import MeanShift
+from .cuda.points_ops import PointsOps
+from .device import DeviceArray, device_ptr, get_runtime
+from .engine.buffer import GpuBuffer
+
+
+class HandPipeline:
+    def __init__(self, layered_rdf, depth_dims, labels_reduce, eval_to_train_dim_ratio, mean_shift_rounds,
+                 mean_shift_variances, fingertip_idxes, intrinsics, plane, depth_mm_level=0):
+        """depth_dims = (DIM_Y, DIM_X); intrinsics = (fx, fy, ppx, ppy) of the depth stream; plane = the calibrated
+        plane's 4x4 matrix (calibrated_plane.plane); fingertip_idxes = 1-based composite label ids (3d_bz.py:112)."""
+        self._rt = get_runtime()
+        self._lib = self._rt.lib
+        self.layered_rdf = layered_rdf
+        self.DIM_Y, self.DIM_X = int(depth_dims[0]), int(depth_dims[1])
+        self.LABELS_REDUCE = int(labels_reduce)
+        self.LABELS_DIM_Y, self.LABELS_DIM_X = self.DIM_Y // self.LABELS_REDUCE, self.DIM_X // self.LABELS_REDUCE
+        self.EVAL_TO_TRAIN_DIM_RATIO = float(eval_to_train_dim_ratio)
+        self.depth_mm_level = int(depth_mm_level)
+        self.mean_shift_rounds = int(mean_shift_rounds)
+        self.fingertip_idxes = [int(i) for i in fingertip_idxes]
+        self.intrinsics = tuple(float(v) for v in intrinsics)
+        self.points_ops = PointsOps()
+        self.mean_shift = MeanShift()
+        d, l = (self.DIM_Y, self.DIM_X), (self.LABELS_DIM_Y, self.LABELS_DIM_X)
+        self.depth_image_group = GpuBuffer(d, np.uint16)
+        self.depth_image_2 = GpuBuffer(d, np.uint16)
+        self.labels_image = GpuBuffer(l, np.uint16)
+        self.labels_image_2 = GpuBuffer(l, np.uint16)
+        self.labels_image_rgba = GpuBuffer(l + (4,), np.uint8)
+        self.mean_shift_variances = DeviceArray((len(mean_shift_variances),), np.float32).set(
+            np.asarray(mean_shift_variances, dtype=np.float32))
+        self._ids = DeviceArray((len(self.fingertip_idxes),), np.int32).set(np.asarray(self.fingertip_idxes, np.int32))
+        self._plane = DeviceArray((4, 4), np.float32).set(np.ascontiguousarray(plane, dtype=np.float32))
+        # means [L,2] followed by heights [n_fingertips]: one device->host copy per frame
+        self._L = int(layered_rdf.num_layered_classes)
+        self._result = DeviceArray((self._L * 2 + len(self.fingertip_idxes),), np.float64)
+
+    def run(self, depth_image, depth_image_mm_groups, g_id, flip_x):
+        """depth_image: GpuBuffer uint16 [DIM_Y, DIM_X] (the frame, 0 = no reading);
+        depth_image_mm_groups: GpuBuffer of the hand-group image at mip level depth_mm_level;
+        returns (label_means float64 [L, 2], fingertip heights float64 [n], NaN = "reset" in the reference)."""
+        self._enqueue(depth_image, depth_image_mm_groups, g_id, flip_x)
+        return self._read()
+
+    def capture(self, depth_image, depth_image_mm_groups, g_id, flip_x):
+        """Records the chain for these buffers and arguments into a hipGraph (through torch) and returns a
+        function that replays it on the buffers' current contents and returns what run() returns: one graph
+        launch per hand per frame instead of ~16 kernel launches."""
+        import torch
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):      # warm-up on the capture stream: workspaces, occupancy queries, queue slot
+            self._enqueue(depth_image, depth_image_mm_groups, g_id, flip_x)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            self._enqueue(depth_image, depth_image_mm_groups, g_id, flip_x)
+
+        def replay():
+            graph.replay()
+            return self._read()
+        return replay
+
+    def _read(self):
+        out = self._result.get()
+        return out[:self._L * 2].reshape(self._L, 2), out[self._L * 2:]
+
+    def _enqueue(self, depth_image, depth_image_mm_groups, g_id, flip_x):
+        dims = np.array([self.DIM_X, self.DIM_Y], dtype=np.int32)
+        ldims = np.array([self.LABELS_DIM_X, self.LABELS_DIM_Y], dtype=np.int32)
+        po = self.points_ops
+        self.depth_image_group.cu().fill(0)
+        po.stencil_depth_image_by_group(dims, np.int32(self.depth_mm_level), np.int32(g_id), depth_image_mm_groups.cu(),
+                                        depth_image.cu(), self.depth_image_group.cu())
+        if flip_x:
+            po.flip_x(dims, self.depth_image_group.cu(), self.depth_image_2.cu())
+        else:
+            self.depth_image_2.cu().copy_from(self.depth_image_group.cu())
+        po.convert_0s_to_maxuint(np.int32(self.DIM_X * self.DIM_Y), self.depth_image_2.cu())
+
+        self.layered_rdf.run(self.depth_image_2, self.labels_image, self.EVAL_TO_TRAIN_DIM_RATIO)
+
+        if flip_x:
+            self.labels_image_2.cu().copy_from(self.labels_image.cu())
+            po.flip_x(ldims, self.labels_image_2.cu(), self.labels_image.cu())
+        po.make_rgba_from_labels(np.uint32(self.LABELS_DIM_X), np.uint32(self.LABELS_DIM_Y), np.uint32(self._L),
+                                 self.labels_image.cu(), self.layered_rdf.label_colors.cu(), self.labels_image_rgba.cu())
+
+        means = self.mean_shift.run_device(self.mean_shift_rounds,
+                                           self.labels_image.cu().reshape((1, self.LABELS_DIM_Y, self.LABELS_DIM_X)),
+                                           self._L, self.mean_shift_variances)
+        fx, fy, ppx, ppy = self.intrinsics
+        heights = self._result[self._L * 2:]
+        # z is looked up in the ORIGINAL depth frame (3d_bz.py:515), not the stencilled / flipped one
+        rc = self._lib.rdf_fingertip_heights(means.ptr, self._L, self._ids.ptr, len(self.fingertip_idxes),
+                                             device_ptr(depth_image.cu()), self.DIM_X, self.DIM_Y, self.LABELS_REDUCE,
+                                             fx, fy, ppx, ppy, self._plane.ptr, heights.ptr, self._rt.stream())
+        _lib.check(self._lib, rc, "rdf_fingertip_heights")
+        self._result[:self._L * 2].copy_from(means.reshape(self._L * 2))
+        self._result.mark_dirty()

@@ -1,0 +1,99 @@
+"""The whole per-hand chain of the reference's app (3d_bz.py:388-522) on the device, against the same chain built
+from the CPU restatements: stencil -> flip -> 0->65535 -> layered forest -> flip back -> RGBA -> mean shift ->
+fingertip heights."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import mean_shift_numpy as ms_np
+from oracle import points_ops_numpy as po_np
+
+H, W, R = 480, 848, 2
+
+
+def _scene(rdf):
+    """A frame as the camera delivers it (0 = no reading) with two 'hands' (groups 1 and 2)."""
+    synth = rdf.synth
+    a, b = synth.live_frame(4100, H, W), synth.live_frame(4101, H, W)
+    depth = np.zeros((H, W), np.uint16)
+    groups = np.zeros((H, W), np.uint16)
+    for g, f in ((1, a), (2, b)):
+        m = (f != 65535) & (f != 0) & (groups == 0)
+        depth[m] = f[m]
+        groups[m] = g
+    return depth, groups
+
+
+def _config(rdf):
+    synth = rdf.synth
+    f0, f1 = synth.forest(3, 9, 4, "trained", 60), synth.forest(3, 10, 5, "trained", 70)
+    conditions = [[0, 1], [0, 2], [1, 3], [0, 3], [0, 4], [0, 5], [0, 6], [0, 7]]
+    colors = [[10 * i, 255 - 10 * i, i, 255] for i in range(1, 8)]
+    return f0, f1, conditions, colors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flip_x", [False, True])
+def test_hand_pipeline_matches_the_chain_of_restatements(flip_x, rdf, gpu_runtime, oracle):
+    pl = importlib.import_module("3d-beats_amd.pipeline")
+    depth, groups = _scene(rdf)
+    f0, f1, conditions, colors = _config(rdf)
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(f0)},
+                      {"model": rdf.DecisionForest.from_numpy(f1), "filter_model": 0, "filter_model_class": 3}],
+           "conditions": conditions, "label_colors": colors}
+    lf = rdf.LayeredDecisionForest(cfg, (H, W), R)
+    L = lf.num_layered_classes
+    assert L == 7
+    variances = np.linspace(20., 60., L).astype(np.float32)
+    plane = (np.eye(4) + 0.05 * np.random.default_rng(3).standard_normal((4, 4))).astype(np.float32)
+    intr = (421.3, 420.9, 423.1, 238.6)
+    tips = [3, 4, 5, 6, 7]
+    ratio = 0.75
+    pipe = pl.HandPipeline(lf, (H, W), R, ratio, 5, variances, tips, intr, plane)
+    dbuf, gbuf = rdf.GpuBuffer((H, W), np.uint16), rdf.GpuBuffer((H, W), np.uint16)
+    dbuf.cu().set(depth)
+    gbuf.cu().set(groups)
+
+    for g_id in (1, 2):
+        means, heights = pipe.run(dbuf, gbuf, g_id, flip_x)
+
+        # ---- the same chain from the restatements ----
+        d_group = po_np.stencil_depth_image_by_group(W, H, 0, g_id, groups, depth, np.zeros((H, W), np.uint16))
+        d2 = d_group[:, ::-1].copy() if flip_x else d_group.copy()
+        po_np.convert_0s_to_maxuint(d2)
+        l0 = np.full((1, H // R, W // R), 65535, np.uint16)
+        l1, comp = l0.copy(), l0.copy()
+        oracle.eval_forest(d2[None], f0, l0, R, None, None, ratio)
+        oracle.eval_forest(d2[None], f1, l1, R, l0, 3, ratio)
+        oracle.composite([l0[0], l1[0]], np.array(conditions, np.int32), comp)
+        labels = comp[0][:, ::-1].copy() if flip_x else comp[0]
+        rgba = po_np.make_rgba_from_labels(labels, np.array(colors, np.uint8), np.zeros((H // R, W // R, 4), np.uint8))
+        want_means = ms_np.mean_shift(labels[None], L, variances, 5)
+        want_h = ms_np.fingertip_heights(want_means, tips, depth, R, *intr, plane)
+
+        assert np.array_equal(pipe.depth_image_2.cu().get(), d2)
+        assert np.array_equal(pipe.labels_image.cu().get(), labels)
+        assert (labels != 65535).sum() > 1000 and len(np.unique(labels)) >= 4
+        got_rgba = pipe.labels_image_rgba.cu().get()
+        lab_ok = (labels != 0) & (labels != 65535)
+        assert np.array_equal(got_rgba[lab_ok], rgba[lab_ok])   # other texels keep what the buffer held before
+        assert np.array_equal(np.isnan(means), np.isnan(want_means))
+        ok = ~np.isnan(want_means)
+        assert np.abs(means[ok] - want_means[ok]).max() < 1e-9
+        assert np.array_equal(np.isnan(heights), np.isnan(want_h))
+        okh = ~np.isnan(want_h)
+        assert np.allclose(heights[okh], want_h[okh], rtol=1e-6, atol=1e-6)
+        # and the frame is reproducible bit for bit
+        means2, heights2 = pipe.run(dbuf, gbuf, g_id, flip_x)
+        assert np.array_equal(means.view(np.uint64), means2.view(np.uint64))
+        assert np.array_equal(heights.view(np.uint64), heights2.view(np.uint64))
+    # the same chain as a captured graph, replayed on a changed frame
+    replay = pipe.capture(dbuf, gbuf, 2, flip_x)
+    m_a, h_a = replay()
+    assert np.array_equal(m_a.view(np.uint64), means.view(np.uint64)) and np.array_equal(h_a.view(np.uint64), heights.view(np.uint64))
+    gbuf.cu().set(np.where(groups == 1, 2, np.where(groups == 2, 1, 0)).astype(np.uint16))   # swap the hands
+    m_b, h_b = replay()
+    m_c, h_c = pipe.run(dbuf, gbuf, 2, flip_x)
+    assert np.array_equal(m_b.view(np.uint64), m_c.view(np.uint64)) and np.array_equal(h_b.view(np.uint64), h_c.view(np.uint64))
+    assert not np.array_equal(m_b.view(np.uint64), m_a.view(np.uint64))
