@@ -61,12 +61,17 @@ struct HistArgs {
     uint32_t n_tiles, tiles_x, tiles_y;
     int W, H, P, C, NB, node_start, node_end;
     int left_only;   // count the left children only (the right ones follow from the parents, k_train_right_counts)
+    uint32_t *tmp;   // PAIRS: 32-bit counters [pair][bin][2], two proposals per 64-bit atomic (k_train_unpack_pairs)
+    int Ppad;
 };
 
 // evaluate_random_features (tree_train.cu:4-64).
 // Counts go straight to the global histogram, aggregated per wave first (see "peers" below).  A workgroup-
 // private LDS histogram for the upper levels was measured and dropped: with the per-wave aggregation it was
 // no faster at any level (r01 notes in DESIGN.md).
+// PAIRS: left children only, into a.tmp: the counters of proposals j and j+1 of one bin are the two halves of one
+// 64-bit word, so ONE atomic serves two proposals (a bin's total is < 2^31 pixels: no carry between the halves).
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
 {
     __shared__ uint16_t s_buf[8 + kTH * kTW];
@@ -168,6 +173,27 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
                 pu[k] = probe_issue(pc, cux, cuy);
                 pv[k] = probe_issue(pc, cvx, cvy);
             }
+            if (PAIRS) {
+                unsigned n[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const float f = zero_depth ? 0.0f : (float)(probe_value(pu[k]) - probe_value(pv[k]));
+                    const u64 left = __ballot(live && f < thr[k]);      // tree_train.cu:57-58
+                    n[k] = (jb + k) < j1 ? (unsigned)__popcll(peers & left) : 0u;
+                }
+                // the lowest lane of each (node, class) group adds the group's left counts, two proposals at a time
+                if (live && lane == __ffsll((long long)peers) - 1) {
+                    // tmp[pair][bin][2]: like the reference's [proposal][bin] layout, a bin's pairs lie far apart, so the
+                    // adds of one bin spread over the L2 channels (a [bin][proposal] layout ran 2x slower)
+                    u64 *cell = reinterpret_cast<u64 *>(a.tmp) + (size_t)(jb >> 1) * a.NB * a.C + bin0;
+#pragma unroll
+                    for (int k = 0; k < kBatch; k += 2) {
+                        const u64 v = (u64)n[k] | ((u64)n[k + 1] << 32);
+                        if (v) atomicAdd(cell + (size_t)(k >> 1) * a.NB * a.C, v);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
                 const int j = jb + k;
@@ -184,6 +210,21 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
             }
         }
     }
+}
+
+// tmp[pair][bin][2] (32-bit halves, written by k_train_histogram<true>) -> counts[j][bin] (64-bit, the layout of the
+// reference); tmp is left zeroed for the next call.
+__global__ __launch_bounds__(256) void k_train_unpack_pairs(uint32_t *tmp, int n_bins, int P, int Ppad, int NB, int C, u64 *counts)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (pair, bin, half), bins < n_bins only
+    if (t >= (long long)(Ppad / 2) * n_bins * 2) return;
+    const int half = (int)(t & 1), bin = (int)((t >> 1) % n_bins), pair = (int)((t >> 1) / n_bins);
+    uint32_t *cell = tmp + ((size_t)pair * NB * C + bin) * 2 + half;
+    const uint32_t v = *cell;
+    if (!v) return;
+    *cell = 0u;
+    const int j = pair * 2 + half;
+    if (j < P) counts[(size_t)j * NB * C + bin] += v;
 }
 
 // Right-child counts from the parents: every live pixel of a node goes either left or right, so
@@ -383,9 +424,12 @@ int rdf_train_init(const uint16_t *labels, size_t n_px, int n_classes, int32_t *
     return (int)hipGetLastError();
 }
 
+static int pairs_ppad(int n_proposals) { return (n_proposals + kBatch - 1) / kBatch * kBatch; }
+
 static int train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
                            int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes, int node_start,
-                           int node_end, int nodes_per_block, unsigned long long *counts, int left_only, void *stream)
+                           int node_end, int nodes_per_block, unsigned long long *counts, int left_only, void *workspace,
+                           void *stream)
 {
     if (n_img < 0 || dim_x < 0 || dim_y < 0 || n_proposals < 0 || n_classes < 1 || n_classes > kMaxClasses ||
         nodes_per_block < 1 || node_end - node_start > nodes_per_block || node_start < 0)
@@ -398,6 +442,8 @@ static int train_histogram(const uint16_t *depth, const uint16_t *labels, const 
     a.W = dim_x; a.H = dim_y; a.P = n_proposals; a.C = n_classes; a.NB = nodes_per_block;
     a.node_start = node_start; a.node_end = node_end;
     a.left_only = left_only;
+    a.tmp = reinterpret_cast<uint32_t *>(workspace);
+    a.Ppad = pairs_ppad(n_proposals);
     a.tiles_x = (uint32_t)(dim_x + kCols - 1) / kCols;
     a.tiles_y = (uint32_t)(dim_y + kRows - 1) / kRows;
     const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
@@ -407,8 +453,23 @@ static int train_histogram(const uint16_t *depth, const uint16_t *labels, const 
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     long long grid = (long long)cus * 8;
     if (grid > n_tiles) grid = n_tiles;
-    hipLaunchKernelGGL(k_train_histogram, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-    return (int)hipGetLastError();
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!workspace) {
+        hipLaunchKernelGGL(k_train_histogram<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
+        return (int)hipGetLastError();
+    }
+    if (((uintptr_t)workspace & 7u) != 0) return RDF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_train_histogram<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const int n_bins = (node_end - node_start) * n_classes;
+    const long long n = (long long)n_bins * a.Ppad;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_train_unpack_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.tmp, n_bins, n_proposals,
+                           a.Ppad, nodes_per_block, n_classes, counts);
+        e = hipGetLastError();
+    }
+    return (int)e;
 }
 
 int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
@@ -416,7 +477,7 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
                         int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
 {
     return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
-                           node_start, node_end, nodes_per_block, counts, 0, stream);
+                           node_start, node_end, nodes_per_block, counts, 0, nullptr, stream);
 }
 
 int rdf_train_histogram_left(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
@@ -424,7 +485,23 @@ int rdf_train_histogram_left(const uint16_t *depth, const uint16_t *labels, cons
                              int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
 {
     return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
-                           node_start, node_end, nodes_per_block, counts, 1, stream);
+                           node_start, node_end, nodes_per_block, counts, 1, nullptr, stream);
+}
+
+size_t rdf_train_histogram_workspace_bytes(int n_proposals, int nodes_per_block, int n_classes)
+{
+    if (n_proposals < 0 || nodes_per_block < 0 || n_classes < 0) return 0;
+    return (size_t)nodes_per_block * (size_t)n_classes * (size_t)pairs_ppad(n_proposals) * sizeof(uint32_t);
+}
+
+int rdf_train_histogram_left_ws(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                                int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
+                                int node_start, int node_end, int nodes_per_block, unsigned long long *counts,
+                                void *workspace, void *stream)
+{
+    if (!workspace) return RDF_ERR_NULL_PTR;
+    return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
+                           node_start, node_end, nodes_per_block, counts, 1, workspace, stream);
 }
 
 int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,

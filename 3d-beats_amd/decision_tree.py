@@ -379,6 +379,8 @@ class DecisionTreeTrainer:
         self.current_proposals_block = DeviceArray((P, 5), np.float32)
         self.nodes_per_block = min(self.MAX_LEAF_NODES, self.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK)
         self.current_next_node_counts_by_feature_cu_block = DeviceArray((P, self.nodes_per_block, C), np.uint64)
+        ws = int(self._lib.rdf_train_histogram_workspace_bytes(P, self.nodes_per_block, C))
+        self._hist_workspace = DeviceArray((max(ws, 8),), np.uint8).fill(0)   # the histogram calls keep it zero
 
         # the whole training set, resident
         self.depth_cu = DeviceArray(shape, np.uint16)
@@ -430,11 +432,12 @@ class DecisionTreeTrainer:
                     self.current_next_node_counts_by_feature_cu_block.fill(0)
                     # evaluate_random_features, as two calls: the kernel counts the left children, the right ones
                     # follow from the parents' counts (the whole training set is counted in this one call)
-                    chk(lib.rdf_train_histogram_left(self.depth_cu.ptr, self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr,
-                                                     n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
-                                                     node_block_start, node_block_end, NB,
-                                                     self.current_next_node_counts_by_feature_cu_block.ptr, st()),
-                        "rdf_train_histogram_left")
+                    chk(lib.rdf_train_histogram_left_ws(self.depth_cu.ptr, self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr,
+                                                        n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
+                                                        node_block_start, node_block_end, NB,
+                                                        self.current_next_node_counts_by_feature_cu_block.ptr,
+                                                        self._hist_workspace.ptr, st()),
+                        "rdf_train_histogram_left_ws")
                     chk(lib.rdf_train_right_counts(num_active_nodes, self.active_nodes_cu.ptr, P, NB, node_block_start,
                                                    node_block_end, C, self.node_counts_cu.ptr,
                                                    self.current_next_node_counts_by_feature_cu_block.ptr, st()),

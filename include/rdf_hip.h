@@ -176,6 +176,10 @@ int rdf_make_rgba_from_labels(int dim_x, int dim_y, int num_colors, const uint16
  *                           every live pixel whose children fall in [node_start, node_end); counts is uint64
  *                           [n_proposals][nodes_per_block][n_classes], zeroed by the caller; proposals float32 [P][5]
  * rdf_train_histogram_left  the same, but only the LEFT children are counted (half the atomics, which bound the kernel);
+ * rdf_train_histogram_left_ws  the same result as rdf_train_histogram_left, faster: it counts into a caller-owned
+ *                           workspace of rdf_train_histogram_workspace_bytes() bytes (8-byte aligned, ZERO before the first
+ *                           call; every call leaves it zero) where one 64-bit atomic serves two proposals, then adds
+ *                           the workspace into `counts`
  * rdf_train_right_counts    then fills counts[j][right][c] = parent_counts[node][c] - counts[j][left][c] for the children of
  *                           the active nodes that fall in [node_start, node_end).  Call it once, after every image has
  *                           been counted; the pair leaves `counts` exactly as rdf_train_histogram does
@@ -193,6 +197,11 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
 int rdf_train_histogram_left(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
                              int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
                              int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream);
+size_t rdf_train_histogram_workspace_bytes(int n_proposals, int nodes_per_block, int n_classes);
+int rdf_train_histogram_left_ws(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
+                                int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
+                                int node_start, int node_end, int nodes_per_block, unsigned long long *counts,
+                                void *workspace, void *stream);
 int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,
                            int node_start, int node_end, int n_classes, const unsigned long long *parent_counts,
                            unsigned long long *counts, void *stream);

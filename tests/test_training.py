@@ -131,6 +131,16 @@ def test_left_only_histogram_plus_right_counts_equals_full_histogram(rdf, gpu_ru
     left_only = split.get()
     assert lib.rdf_train_right_counts(n_act, trainer.active_nodes_cu.ptr, P, NB, start, end, C, trainer.node_counts_cu.ptr,
                                       split.ptr, st()) == 0
+    # ... and the workspace variant (two proposals per 64-bit atomic) leaves the same left counts and a zero workspace
+    ws_bytes = int(lib.rdf_train_histogram_workspace_bytes(P, NB, C))
+    assert ws_bytes == NB * C * ((P + 3) // 4 * 4) * 4
+    ws = rdf.DeviceArray((ws_bytes,), np.uint8).fill(0)
+    packed = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
+    for _ in range(2):   # twice: the second call relies on the first one having cleaned up
+        packed.fill(0)
+        assert lib.rdf_train_histogram_left_ws(*args, packed.ptr, ws.ptr, st()) == 0
+        assert np.array_equal(packed.get(), left_only)
+        assert not ws.get().any()
     want, got = full.get(), split.get()
     assert want.sum() == P * (nodes_px >= 0).sum()
     assert (left_only[:, 1::2, :] == 0).all() and left_only.sum() < want.sum()
