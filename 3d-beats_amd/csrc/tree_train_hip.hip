@@ -7,7 +7,10 @@
 //     through the scalar cache) with the pixel's depth neighbourhood staged in LDS, where the
 //     reference spends one thread and one 64-bit global atomic per (pixel, proposal);
 //   * a wave covers an 8x8 block of pixels and counts with ballots and popcounts: one atomic per
-//     (node, class, side) the block touches per proposal instead of one per pixel;
+//     (node, class) group the block touches instead of one per pixel -- and, on the fast path
+//     (rdf_train_histogram_left_ws), only for the left children (the right ones follow from the
+//     parents) and for two proposals at a time (32-bit halves of one 64-bit word).  The rate of
+//     scattered global atomics (24e9/s, tools/ubench_atomic.hip) is what bounds this kernel;
 //   * the next level's node list is built by an ordered scan (the reference appends with an atomic
 //     counter, i.e. in scheduler order), so the whole training run is reproducible bit for bit;
 //   * floor((u)/d) uses the shared-reciprocal divide verified exhaustively for inference
