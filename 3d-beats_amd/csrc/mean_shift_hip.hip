@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int kMsBlocks = 64;      // workgroups per round (fixed: it defines the summation order)
-constexpr int kMsThreads = 256;
+constexpr int kMsThreads = 1024;
 constexpr int kMsWaves = kMsThreads / 64;
 constexpr int kMsMaxClasses = 64;
 constexpr uint32_t kNoLabel = 65535u;
