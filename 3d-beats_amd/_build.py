@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rdf_hip.hip")
 SOURCES = [SRC, os.path.join(HERE, "csrc", "mean_shift_hip.hip"), os.path.join(HERE, "csrc", "points_ops_hip.hip"),
            os.path.join(HERE, "csrc", "tree_train_hip.hip")]
-HDR = os.path.join(HERE, "..", "include", "rdf_hip.h")
+HEADERS = [os.path.join(HERE, "..", "include", "rdf_hip.h"), os.path.join(HERE, "csrc", "rdf_device.hpp")]
 SO = os.path.join(HERE, "csrc", "librdf_hip.so")
 
 # No -ffast-math, no -fgpu-flush-denormals-to-zero: the fp32 divide must stay IEEE-correct
@@ -24,7 +24,7 @@ def is_stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + [HDR, __file__])
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + HEADERS + [__file__])
 
 
 def build(force=False, verbose=False):

@@ -44,7 +44,7 @@
 
 namespace {
 
-constexpr int kGroup = 4;          // trees walked interleaved by one lane
+constexpr int kGroup = 4;          // trees walked interleaved by one lane (template GROUP: 1 and 2 for smaller forests)
 constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
 constexpr int kDefaultLdsBudget = 32000;   // node table + depth tile per workgroup
 constexpr int kDefaultHalo = 24;   // depth pixels staged around a tile's centres
@@ -188,7 +188,7 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
 
 // FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
 // a.rows_per_wave rows (latency shape for small launches such as one live frame).
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
 __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -326,42 +326,42 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) pdf[c] = 0.0f;
 
-                for (int kb = 0; kb < a.T; kb += kGroup) {
+                for (int kb = 0; kb < a.T; kb += GROUP) {
                     // Walk state, one word per tree: while walking, the 1-based heap index of the current node
                     // (< 2^31); once a leaf is reached, kDone | ((node - 1) * 2 + side); kIdle for tree slots
                     // beyond T.  "Still walking" is simply (int)h > 0.
                     constexpr uint32_t kDone = 0x80000000u, kIdle = 0xFFFFFFFFu;
-                    uint32_t h[kGroup];
+                    uint32_t h[GROUP];
 #pragma unroll
-                    for (int k = 0; k < kGroup; ++k) h[k] = (kb + k) < a.T ? 1u : kIdle;
+                    for (int k = 0; k < GROUP; ++k) h[k] = (kb + k) < a.T ? 1u : kIdle;
 
                     for (int j = 0; j < a.D; ++j) {
                         bool any = false;
 #pragma unroll
-                        for (int k = 0; k < kGroup; ++k) any |= (int)h[k] > 0;
+                        for (int k = 0; k < GROUP; ++k) any |= (int)h[k] > 0;
                         if (!__any(any)) break;
 
                         const bool in_lds = j < K;
-                        Node n[kGroup];
-                        uint32_t hn[kGroup];   // node to fetch: a finished or idle slot re-reads the root (cheap, discarded)
+                        Node n[GROUP];
+                        uint32_t hn[GROUP];   // node to fetch: a finished or idle slot re-reads the root (cheap, discarded)
 #pragma unroll
-                        for (int k = 0; k < kGroup; ++k) hn[k] = (int)h[k] > 0 ? h[k] : 1u;
+                        for (int k = 0; k < GROUP; ++k) hn[k] = (int)h[k] > 0 ? h[k] : 1u;
                         if (in_lds) {
 #pragma unroll
-                            for (int k = 0; k < kGroup; ++k) {
+                            for (int k = 0; k < GROUP; ++k) {
                                 const uint32_t tk = (uint32_t)min(kb + k, a.T - 1);   // wave-uniform
                                 n[k] = decode_node(lds_nodes[tk * lds_pitch + hn[k]]);
                             }
                         } else if (PACKED) {
 #pragma unroll
-                            for (int k = 0; k < kGroup; ++k) {
+                            for (int k = 0; k < GROUP; ++k) {
                                 const int tk = min(kb + k, a.T - 1);
                                 const char *base = reinterpret_cast<const char *>(a.packed16 + ((size_t)tk << a.D));
                                 n[k] = decode_node(*reinterpret_cast<const uint4 *>(base + hn[k] * 16u));
                             }
                         } else {
 #pragma unroll
-                            for (int k = 0; k < kGroup; ++k) {
+                            for (int k = 0; k < GROUP; ++k) {
                                 const int tk = min(kb + k, a.T - 1);
                                 const float *p = a.forest + ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
                                 n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1]; n[k].bx = a.s * p[2]; n[k].by = a.s * p[3];
@@ -371,16 +371,16 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                         }
 
                         // ---- probe coordinates x + floor((s*u.x)/d) ... (decision_tree_common.hpp:15-22), kept relative to the tile ----
-                        int ux[kGroup], uy[kGroup], vx[kGroup], vy[kGroup];
+                        int ux[GROUP], uy[GROUP], vx[GROUP], vy[GROUP];
                         uint32_t fl = 0u;
 #pragma unroll
-                        for (int k = 0; k < kGroup; ++k) fl |= n[k].flags;
+                        for (int k = 0; k < GROUP; ++k) fl |= n[k].flags;
                         if (__any((fl & kFlagExact) != 0u)) {
                             // some lane holds a node whose numerators are not integer-representable: fetch the
                             // fp32 numerators for those lanes and divide IEEE (every lane: same results)
                             if (PACKED || in_lds) {
 #pragma unroll
-                                for (int k = 0; k < kGroup; ++k) {
+                                for (int k = 0; k < GROUP; ++k) {
                                     if (n[k].flags & kFlagExact) {
                                         const int tk = min(kb + k, a.T - 1);
                                         if (PACKED) {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                                 }
                             }
 #pragma unroll
-                            for (int k = 0; k < kGroup; ++k) {
+                            for (int k = 0; k < GROUP; ++k) {
                                 // lanes on an ordinary node still hold kNumScale * (x + e): same floor (NodeRec16)
                                 const float den = (n[k].flags & kFlagExact) ? df : df_s;
                                 ux[k] = add_wrap(xl, floor_i32(n[k].ax / den));
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             // q0 = a*rcp; rem = a - d*q0 (exact, fma); q = q0 + rem*rcp.  Packed f32 math,
                             // two quotients per instruction.
 #pragma unroll
-                            for (int k = 0; k < kGroup; ++k) {
+                            for (int k = 0; k < GROUP; ++k) {
                                 const f2 nu = {n[k].ax, n[k].ay};
                                 const f2 nv = {n[k].bx, n[k].by};
                                 const f2 qu0 = nu * rcp2;
@@ -425,16 +425,16 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             }
                         }
 
-                        Probe qu[kGroup], qv[kGroup];
+                        Probe qu[GROUP], qv[GROUP];
 #pragma unroll
-                        for (int k = 0; k < kGroup; ++k) {
+                        for (int k = 0; k < GROUP; ++k) {
                             qu[k] = probe_issue(pc, ux[k], uy[k]);
                             qv[k] = probe_issue(pc, vx[k], vy[k]);
                         }
 
                         // ---- decide (tree_eval.cu:107-121), branch-free ----
 #pragma unroll
-                        for (int k = 0; k < kGroup; ++k) {
+                        for (int k = 0; k < GROUP; ++k) {
                             const bool walking = (int)h[k] > 0;
                             if (STATS && c0 == 0) st_lv += walking ? 1u : 0u;
                             const uint32_t side = (probe_value(qu[k]) - probe_value(qv[k])) < n[k].t ? 0u : 1u;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 
                     // leaf PDFs, strictly in tree order (canonical sum order)
 #pragma unroll
-                    for (int k = 0; k < kGroup; ++k) {
+                    for (int k = 0; k < GROUP; ++k) {
                         if ((int)h[k] < 0 && h[k] != kIdle) {
                             const uint32_t leaf = (h[k] & ~kDone) - 2u;   // (node - 1) * 2 + side
                             any_leaf = true;
@@ -665,10 +665,10 @@ struct LaunchGeom {
 };
 std::map<std::tuple<int, const void *, int>, int> g_occ_cache;   // (device, kernel, LDS bytes) -> workgroups per CU
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
-int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
+int launch_group(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, FULLROWS>;
+    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
@@ -696,6 +696,19 @@ int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, a);
     return (int)hipGetLastError();
+}
+
+// A lane walks GROUP trees interleaved.  Forests of one or two trees (and `rdf_eval_tree`) get kernels without the
+// idle slots of the 4-wide one (measured: T = 1 costs 54 % of T = 4 with idle slots); these exist for the default
+// workgroup size only.
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
+int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+{
+    if (BLOCK == 256 && !STATS) {
+        if (a.T == 1) return launch_group<256, PACKED, CMAX, false, FULLROWS, 1>(a, lds_bytes, cus, st);
+        if (a.T == 2) return launch_group<256, PACKED, CMAX, false, FULLROWS, 2>(a, lds_bytes, cus, st);
+    }
+    return launch_group<BLOCK, PACKED, CMAX, STATS, FULLROWS, kGroup>(a, lds_bytes, cus, st);
 }
 
 template <int BLOCK, bool PACKED, int CMAX, bool STATS>
