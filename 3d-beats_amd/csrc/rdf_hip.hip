@@ -698,7 +698,7 @@ int launch_group(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
     return (int)hipGetLastError();
 }
 
-// A lane walks GROUP trees interleaved.  Forests of one or two trees (and `rdf_eval_tree`) get kernels without the
+// A lane walks GROUP trees interleaved.  Forests of one, two, three or six trees (and `rdf_eval_tree`) get kernels without the
 // idle slots of the 4-wide one (measured: T = 1 costs 54 % of T = 4 with idle slots); these exist for the default
 // workgroup size only.
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
@@ -707,6 +707,7 @@ int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
     if (BLOCK == 256 && !STATS) {
         if (a.T == 1) return launch_group<256, PACKED, CMAX, false, FULLROWS, 1>(a, lds_bytes, cus, st);
         if (a.T == 2) return launch_group<256, PACKED, CMAX, false, FULLROWS, 2>(a, lds_bytes, cus, st);
+        if (a.T == 3 || a.T == 6) return launch_group<256, PACKED, CMAX, false, FULLROWS, 3>(a, lds_bytes, cus, st);
     }
     return launch_group<BLOCK, PACKED, CMAX, STATS, FULLROWS, kGroup>(a, lds_bytes, cus, st);
 }

@@ -139,6 +139,9 @@ SWEEP = [
     (9, 7, 17, "trained", 1, 33, 65, 1, 1.0, False),
     (4, 10, 33, "full", 1, 20, 70, 1, 1.0, True),
     (4, 1, 4, "full", 1, 9, 11, 1, 1.0, False),
+    (6, 10, 4, "trained", 2, 70, 131, 1, 1.0, False),   # two passes of the 3-wide kernel
+    (1, 14, 4, "full", 2, 64, 200, 1, 1.0, True),       # 1-wide kernel, deep, filtered
+    (2, 13, 5, "trained", 1, 90, 90, 2, 1.5, False),    # 2-wide kernel, 8-class accumulator
 ]
 
 
