@@ -630,16 +630,21 @@ int device_info(DeviceInfo *out)
 std::mutex g_sched_mu;
 std::map<std::pair<int, void *>, int> g_sched_slot;
 std::map<int, unsigned int *> g_sched_base;     // device -> address of g_sched on that device
-int g_sched_mode = -1;                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic
+int g_sched_mode = -1;                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic, 2 one tile per workgroup
 
-unsigned int *sched_slot(void *stream)
+int sched_mode()
 {
     int mode = g_sched_mode;
     if (mode < 0) {
         const char *v = getenv("RDF_SCHED");
-        mode = (v && strcmp(v, "static") == 0) ? 0 : 1;
+        mode = (v && strcmp(v, "static") == 0) ? 0 : (v && strcmp(v, "tile") == 0) ? 2 : 1;
     }
-    if (mode == 0) return nullptr;
+    return mode;
+}
+
+unsigned int *sched_slot(void *stream)
+{
+    if (sched_mode() != 1) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_sched_mu);
@@ -690,8 +695,10 @@ int launch_group(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
         std::lock_guard<std::mutex> lock(g_sched_mu);
         g_occ_cache[key] = per_cu;
     }
-    // persistent workgroups: as many as are resident at once, never more than there are tiles
-    long long grid = (long long)cus * per_cu;
+    // persistent workgroups: as many as are resident at once, never more than there are tiles.  Mode 2 launches one
+    // workgroup per tile instead (8 % slower alone: the node table is staged per tile) -- workgroups then retire all
+    // the time, so a concurrent kernel on another stream (RCCL's) finds free slots at once.
+    long long grid = sched_mode() == 2 ? (long long)a.n_tiles : (long long)cus * per_cu;
     if (grid > (long long)a.n_tiles) grid = a.n_tiles;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, a);

@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="only the timed batch (no cfg2/cfg3/PCIe/CPU legs): "
                     "what tools/profile.sh traces so that rocprofv3's per-kernel average is the headline kernel's")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
+    ap.add_argument("--scheduler", default="dynamic", choices=["dynamic", "static", "tile"],
+                    help="tile schedule of the forest kernel: persistent workgroups on a device-side queue (default), "
+                         "persistent with static striding, or one workgroup per tile (non-persistent: 8 %% slower alone, "
+                         "but a concurrent RCCL kernel never waits for a free slot)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
                     "rehearse the control flow with several ranks on one GPU)")
     return ap.parse_args()
@@ -137,6 +141,7 @@ def main():
     depth = rdf.to_device(frames_np)
     labels = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
     ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
+    lib.rdf_set_scheduler({"dynamic": 1, "static": 0, "tile": 2}[a.scheduler])
     if not a.unpacked:
         forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
     # N>1: one launch per step; the gather of step s overlaps the evaluation of step s+1 (two label buffers);
@@ -220,7 +225,7 @@ def main():
                                + (f"labels gathered to rank 0 ({a.backend}) inside the timed region" if world > 1 else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
                    "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
-                   "pipeline_chunks": chunks, "gather_overlap": ("next step" if overlapped else ("in-step chunks" if world > 1 else None)), "sharding": f"frames x{world}, forest replicated",
+                   "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "gather_overlap": ("next step" if overlapped else ("in-step chunks" if world > 1 else None)), "sharding": f"frames x{world}, forest replicated",
                    "gather_check": gather_check},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),

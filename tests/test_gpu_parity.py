@@ -161,10 +161,10 @@ def test_random_sweep_bit_exact(cfg, path, rdf, evs, oracle):
 
 @pytest.mark.parametrize("block,lds,halo,sched", [(256, 0, 16, 1), (256, 4096, 0, 1), (512, 81920, 16, 0),
                                                   (1024, 163840, 40, 1), (1024, 0, 3, 0), (256, 81920, 200, 1),
-                                                  (512, 40000, 7, 1)])
+                                                  (512, 40000, 7, 1), (256, 0, 24, 2), (512, 20000, 8, 2)])
 def test_launch_geometry_does_not_change_results(block, lds, halo, sched, rdf, gpu_runtime, evs, oracle):
     """Workgroup size, LDS budget (levels held in LDS), staged-tile halo (incl. 'tile does not fit')
-    and static vs dynamic tile queue are performance knobs only."""
+    and the tile schedule (static, dynamic queue, one tile per workgroup) are performance knobs only."""
     synth = rdf.synth
     forest = synth.forest(4, 12, 4, "trained")
     depth = synth.frames(["live", "dense", "live"], 700, 120, 200)
