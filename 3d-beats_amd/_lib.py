@@ -52,6 +52,9 @@ SIGNATURES = {
     "rdf_train_update_pixels": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                          _c_void_p]),
     "rdf_fill_u16": (_c_int, [_c_void_p, _c_size_t, ctypes.c_uint16, _c_void_p]),
+    "rdf_stream_create_with_reserved_cus": (_c_int, [_c_void_p, _c_int]),
+    "rdf_stream_destroy": (_c_int, [_c_void_p]),
+    "rdf_debug_fat_kernel": (_c_int, [_c_int, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "rdf_debug_floor_i32": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_debug_div_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_set_lds_budget_bytes": (None, [_c_int]),

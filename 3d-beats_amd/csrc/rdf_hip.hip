@@ -38,6 +38,7 @@
 #include <tuple>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "../../include/rdf_hip.h"
 #include "rdf_device.hpp"
@@ -575,6 +576,21 @@ __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *dst, size_t n, uint1
     for (size_t i = tail0 + gid; i < n; i += stride) dst[i] = v;
 }
 
+// A kernel with the resource footprint of RCCL's send/recv kernel on gfx950 (rcclGenericKernel in librccl.so:
+// 256 threads, ~280 VGPRs, 19.7 KB of LDS -- one workgroup fills the register files of a whole CU), spinning for a
+// given time.  tools/ubench_overlap.py uses it to show when such a kernel can start next to the forest kernel.
+__global__ __launch_bounds__(256) void k_debug_fat(unsigned long long spin_ticks, unsigned long long *t_start)
+{
+    __shared__ unsigned int pad[19744 / 4];
+    asm volatile("v_mov_b32 v250, 0" ::: "v250");           // allocates > 250 VGPRs per wave
+    pad[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0 && t_start) t_start[blockIdx.x] = t0;
+    while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
+    if (pad[(threadIdx.x + 1) & 255] == 0xFFFFFFFFu && t_start) t_start[0] = 0;   // keeps pad alive
+}
+
 __global__ void k_debug_floor(const float *in, int32_t *out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,6 +679,26 @@ unsigned int *sched_slot(void *stream)
         it = g_sched_slot.emplace(key, used).first;
     }
     return bit->second + 2 * it->second;
+}
+
+// CUs a stream's kernels may run on (hipExtStreamCreateWithCUMask), cached per stream handle.
+std::map<std::pair<int, void *>, int> g_stream_cus;
+int usable_cus(hipStream_t st, int device_cus)
+{
+    if (!st) return device_cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return device_cus;
+    const auto key = std::make_pair(dev, reinterpret_cast<void *>(st));
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    auto it = g_stream_cus.find(key);
+    if (it != g_stream_cus.end()) return it->second;
+    uint32_t mask[32] = {0};
+    int n = 0;
+    if (hipExtStreamGetCUMask(st, 32, mask) == hipSuccess)
+        for (int i = 0; i < 32; ++i) n += __builtin_popcount(mask[i]);
+    if (n < 1 || n > device_cus) n = device_cus;
+    g_stream_cus.emplace(key, n);
+    return n;
 }
 
 struct LaunchGeom {
@@ -839,11 +875,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     a.sched = sched_slot(stream);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int cus = usable_cus(st, di.cus);   // a CU-masked stream holds fewer persistent workgroups
     if (stats) {
-        return packed ? launch_block<true, true>(block, a, lds_bytes, di.cus, st)
-                      : launch_block<false, true>(block, a, lds_bytes, di.cus, st);
+        return packed ? launch_block<true, true>(block, a, lds_bytes, cus, st)
+                      : launch_block<false, true>(block, a, lds_bytes, cus, st);
     }
-    return packed ? launch_block<true, false>(block, a, lds_bytes, di.cus, st)
+    return packed ? launch_block<true, false>(block, a, lds_bytes, cus, st)
                   : launch_block<false, false>(block, a, lds_bytes, di.cus, st);
 }
 
@@ -998,6 +1035,47 @@ void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
 void rdf_set_halo(int pixels) { g_halo = pixels; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }
+
+int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved)
+{
+    // A stream whose kernels never run on the first `n_reserved` CUs of hipExtStreamCreateWithCUMask's numbering.
+    // The forest kernel's persistent workgroups fill every CU they may use, and a kernel as fat as RCCL's send/recv
+    // kernel cannot squeeze in beside them (one of its workgroups needs the register files of a whole CU: measured,
+    // tools/ubench_overlap.py -- it starts only when the forest launch drains).  CUs that the compute stream never
+    // touches are where such kernels run while a forest launch is in flight.  The numbering is shader-engine-minor on
+    // gfx950 (bit i = CU i/32 of shader engine i%32, measured with the same tool), and workgroups are dealt to shader
+    // engines without regard to free CUs, so the useful amounts are multiples of 32: one CU in EVERY shader engine.
+    if (!stream || n_reserved < 1) return RDF_ERR_BAD_ARG;
+    DeviceInfo di;
+    const int rc = device_info(&di);
+    if (rc != 0) return rc;
+    if (n_reserved >= di.cus) return RDF_ERR_BAD_ARG;
+    const int words = (di.cus + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int cu = n_reserved; cu < di.cus; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+    hipStream_t st;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data());
+    if (e != hipSuccess) return (int)e;
+    *stream = st;
+    return RDF_OK;
+}
+int rdf_stream_destroy(void *stream)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        for (auto it = g_stream_cus.begin(); it != g_stream_cus.end();)
+            it = it->first.second == stream ? g_stream_cus.erase(it) : std::next(it);
+    }
+    return (int)hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+}
+
+int rdf_debug_fat_kernel(int n_workgroups, unsigned long long spin_ticks, unsigned long long *t_start, void *stream)
+{
+    if (n_workgroups < 1) return RDF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_debug_fat, dim3((unsigned)n_workgroups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       spin_ticks, t_start);
+    return (int)hipGetLastError();
+}
 
 int rdf_event_create(void **event)
 {

@@ -54,6 +54,8 @@ def parse():
                     help="tile schedule of the forest kernel: persistent workgroups on a device-side queue (default), "
                          "persistent with static striding, or one workgroup per tile (non-persistent: 8 %% slower alone, "
                          "but a concurrent RCCL kernel never waits for a free slot)")
+    ap.add_argument("--reserve-cus", type=int, default=-1, help="run the forest kernel on a stream that leaves this many CUs "
+                    "(one per shader engine = 32) to RCCL's kernels; -1: 32 at N>1, 0 at N=1 (DESIGN.md section 6)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
                     "rehearse the control flow with several ranks on one GPU)")
     return ap.parse_args()
@@ -166,6 +168,24 @@ def main():
     stats = dstats.get()
     alg_bytes = synth.algorithmic_bytes(F, H, W, 1, False, C, stats)
 
+    # ---- N>1: the compute stream leaves one CU per shader engine to RCCL (its send/recv kernel cannot start beside the
+    # forest kernel's persistent workgroups otherwise: tools/ubench_overlap.py) ----
+    reserve = a.reserve_cus if a.reserve_cus >= 0 else (32 if world > 1 else 0)
+    compute_stream, masked_handle = None, None
+    if reserve > 0:
+        import ctypes
+        h = ctypes.c_void_p()
+        rc_m = lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), reserve)
+        if rc_m == 0:
+            masked_handle = h
+            compute_stream = torch.cuda.ExternalStream(h.value)
+        else:
+            print(f"rank {rank}: no CU-masked stream ({lib.rdf_error_string(rc_m)}); using the current stream", file=sys.stderr)
+            reserve = 0
+    torch.cuda.synchronize()
+    import contextlib
+    stream_ctx = torch.cuda.stream(compute_stream) if compute_stream is not None else contextlib.nullcontext()
+
     # ---- timed region ----
     def sync_all():
         torch.cuda.synchronize()
@@ -173,19 +193,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        one_step()
-    sharded.drain()
-    evs = Events(rt, 2 * a.steps)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        evs.record(2 * i)
-        one_step()
-        evs.record(2 * i + 1)
-    sharded.drain()      # every step's label maps are on rank 0 before the clock stops
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    with stream_ctx:
+        for _ in range(a.warmup):
+            one_step()
+        sharded.drain()
+        evs = Events(rt, 2 * a.steps)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            evs.record(2 * i)
+            one_step()
+            evs.record(2 * i + 1)
+        sharded.drain()      # every step's label maps are on rank 0 before the clock stops
+        sync_all()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,7 +246,7 @@ def main():
                                + (f"labels gathered to rank 0 ({a.backend}) inside the timed region" if world > 1 else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
                    "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
-                   "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "gather_overlap": ("next step" if overlapped else ("in-step chunks" if world > 1 else None)), "sharding": f"frames x{world}, forest replicated",
+                   "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": reserve, "gather_overlap": ("next step" if overlapped else ("in-step chunks" if world > 1 else None)), "sharding": f"frames x{world}, forest replicated",
                    "gather_check": gather_check},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -218,6 +218,14 @@ int rdf_train_update_pixels(const uint16_t *depth, int n_img, int dim_x, int dim
 /* GPUArray.fill(65535) of src/decision_tree.py:237-240 for uint16 buffers. */
 int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
 
+/* A stream whose kernels leave the first n_reserved CUs (hipExtStreamCreateWithCUMask numbering; use a multiple of 32 =
+ * one CU per shader engine on MI355X) to other streams, for running the forest kernel next to RCCL: DESIGN.md section 6.
+ * rdf_stream_destroy releases it. */
+int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved);
+int rdf_stream_destroy(void *stream);
+/* Test hook: n_workgroups workgroups with RCCL's send/recv kernel's footprint (256 threads, >250 VGPRs, 19.7 KB LDS) that
+ * record their start time (wall_clock64 ticks, 100 MHz) in t_start[workgroup] and spin for spin_ticks. */
+int rdf_debug_fat_kernel(int n_workgroups, unsigned long long spin_ticks, unsigned long long *t_start, void *stream);
 /* Test hook: out[i] = __float2int_rd(in[i]) as the kernels compute it (floor, saturate, NaN -> 0). */
 int rdf_debug_floor_i32(const float *in, int32_t *out, size_t n, void *stream);
 /* Test hook: out[i] = num[i] / den[i] as the kernels compute it (IEEE fp32 divide). */
