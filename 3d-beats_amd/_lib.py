@@ -54,6 +54,12 @@ SIGNATURES = {
     "rdf_fill_u16": (_c_int, [_c_void_p, _c_size_t, ctypes.c_uint16, _c_void_p]),
     "rdf_stream_create_with_reserved_cus": (_c_int, [_c_void_p, _c_int]),
     "rdf_stream_destroy": (_c_int, [_c_void_p]),
+    "rdf_device_malloc": (_c_int, [_c_void_p, _c_size_t]),
+    "rdf_device_free": (_c_int, [_c_void_p]),
+    "rdf_ipc_export": (_c_int, [_c_void_p, _c_void_p]),
+    "rdf_ipc_open": (_c_int, [_c_void_p, _c_void_p]),
+    "rdf_ipc_close": (_c_int, [_c_void_p]),
+    "rdf_memcpy_device_async": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_debug_fat_kernel": (_c_int, [_c_int, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "rdf_debug_floor_i32": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_debug_div_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

@@ -1069,6 +1069,39 @@ int rdf_stream_destroy(void *stream)
     return (int)hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
 }
 
+// ---- peer-to-peer plumbing for the multi-GPU gather (3d-beats_amd/distributed.py): the root
+// exports its receive buffer, every other process maps it and copies its shard in with the copy engines ----
+int rdf_device_malloc(void **ptr, size_t bytes)
+{
+    if (!ptr) return RDF_ERR_NULL_PTR;
+    return (int)hipMalloc(ptr, bytes);     // a raw allocation: its base address is what hipIpcGetMemHandle needs
+}
+int rdf_device_free(void *ptr) { return (int)hipFree(ptr); }
+int rdf_ipc_export(void *ptr, unsigned char handle_out[64])
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    if (!ptr || !handle_out) return RDF_ERR_NULL_PTR;
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, ptr);
+    if (e != hipSuccess) return (int)e;
+    memcpy(handle_out, &h, 64);
+    return RDF_OK;
+}
+int rdf_ipc_open(const unsigned char handle[64], void **ptr_out)
+{
+    if (!handle || !ptr_out) return RDF_ERR_NULL_PTR;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    return (int)hipIpcOpenMemHandle(ptr_out, h, hipIpcMemLazyEnablePeerAccess);
+}
+int rdf_ipc_close(void *ptr) { return (int)hipIpcCloseMemHandle(ptr); }
+int rdf_memcpy_device_async(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes == 0) return RDF_OK;
+    if (!dst || !src) return RDF_ERR_NULL_PTR;
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, reinterpret_cast<hipStream_t>(stream));
+}
+
 int rdf_debug_fat_kernel(int n_workgroups, unsigned long long spin_ticks, unsigned long long *t_start, void *stream)
 {
     if (n_workgroups < 1) return RDF_ERR_BAD_ARG;

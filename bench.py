@@ -54,6 +54,10 @@ def parse():
                     help="tile schedule of the forest kernel: persistent workgroups on a device-side queue (default), "
                          "persistent with static striding, or one workgroup per tile (non-persistent: 8 %% slower alone, "
                          "but a concurrent RCCL kernel never waits for a free slot)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl"],
+                    help="how the label maps reach rank 0 at N>1: p2p = every rank copies its shard into rank 0's "
+                         "IPC-mapped buffer with the copy engines (no CU involved); rccl = torch.distributed.gather on a "
+                         "compute stream that leaves 32 CUs to RCCL; auto = p2p if the buffer can be mapped, else rccl")
     ap.add_argument("--reserve-cus", type=int, default=-1, help="run the forest kernel on a stream that leaves this many CUs "
                     "(one per shader engine = 32) to RCCL's kernels; -1: 32 at N>1, 0 at N=1 (DESIGN.md section 6)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
@@ -153,11 +157,27 @@ def main():
     sharded = dmod.ShardedForestEvaluator(ev, forest, F, (H, W), n_chunks=chunks)
     ring = [labels, rdf.DeviceArray((F, H, W), np.uint16).fill(65535)] if overlapped else None
 
+    # N>1, default: peer copies over xGMI by the copy engines (RCCL carries only the control plane); needs HIP IPC
+    # between the ranks' processes, falls back to the RCCL gather if any rank cannot map rank 0's buffer
+    peer = None
+    if world > 1 and a.chunks == 0 and a.gather in ("auto", "p2p"):
+        pg = dmod.PeerCopyGather(world, rank, F * H * W * 2)
+        if pg.ok:
+            peer = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg)
+        elif a.gather == "p2p":
+            sys.exit("--gather p2p: rank 0's receive buffer could not be mapped by every rank")
+    gather_mode = None if world == 1 else ("p2p copy engines" if peer is not None else "rccl gather")
+
     def one_step():
-        if overlapped:
+        if peer is not None:
+            peer.step(depth, ring)
+        elif overlapped:
             sharded.step_overlapped(depth, ring)
         else:
             sharded.step(depth, labels)
+
+    def drain():
+        (peer if peer is not None else sharded).drain()
 
     # ---- algorithmic bytes of one step, from the visit counters of the same walk ----
     dstats = rdf.DeviceArray((3,), np.uint64).fill(0)
@@ -170,7 +190,7 @@ def main():
 
     # ---- N>1: the compute stream leaves one CU per shader engine to RCCL (its send/recv kernel cannot start beside the
     # forest kernel's persistent workgroups otherwise: tools/ubench_overlap.py) ----
-    reserve = a.reserve_cus if a.reserve_cus >= 0 else (32 if world > 1 else 0)
+    reserve = a.reserve_cus if a.reserve_cus >= 0 else (32 if world > 1 and peer is None else 0)
     compute_stream, masked_handle = None, None
     if reserve > 0:
         import ctypes
@@ -196,7 +216,7 @@ def main():
     with stream_ctx:
         for _ in range(a.warmup):
             one_step()
-        sharded.drain()
+        drain()
         evs = Events(rt, 2 * a.steps)
         sync_all()
         t0 = time.perf_counter()
@@ -204,7 +224,7 @@ def main():
             evs.record(2 * i)
             one_step()
             evs.record(2 * i + 1)
-        sharded.drain()      # every step's label maps are on rank 0 before the clock stops
+        drain()              # every step's label maps are on rank 0 before the clock stops
         sync_all()
         elapsed = time.perf_counter() - t0
     if world > 1:
@@ -223,10 +243,11 @@ def main():
         allsums = [torch.zeros_like(sums) for _ in range(world)]
         dist.all_gather(allsums, sums)
         if rank == 0:
-            got = sharded.result()
+            got = peer.result() if peer is not None else sharded.result()
             ok = True
             for g in range(world):
-                part = got[g * F:(g + 1) * F].torch_bytes().view(torch.int16).to(torch.int64)
+                part = got[g * F:(g + 1) * F]
+                part = (part.reshape(-1) if peer is not None else part.torch_bytes().view(torch.int16)).to(torch.int64)
                 chk = torch.stack([part.sum(), (part * (torch.arange(part.numel(), device=part.device) % 8191)).sum()])
                 ok = ok and bool(torch.equal(chk, allsums[g]))
             gather_check = "ok" if ok else "MISMATCH"
@@ -243,10 +264,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{F} x {W}x{H} depth frames per GPU per step (config 4 shard = config 2 frame x {F}; "
                                f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
-                               + (f"labels gathered to rank 0 ({a.backend}) inside the timed region" if world > 1 else "1 GPU"),
+                               + (f"labels gathered to rank 0 ({gather_mode}; control plane {a.backend}) inside the timed region" if world > 1 else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
                    "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
-                   "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": reserve, "gather_overlap": ("next step" if overlapped else ("in-step chunks" if world > 1 else None)), "sharding": f"frames x{world}, forest replicated",
+                   "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": reserve, "gather": gather_mode, "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if world > 1 else None)), "sharding": f"frames x{world}, forest replicated",
                    "gather_check": gather_check},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -352,6 +373,12 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if peer is not None:            # unmap on the peers before rank 0 frees the buffer
+            if rank != 0:
+                pg.close()
+            dist.barrier()
+            if rank == 0:
+                pg.close()
         dist.destroy_process_group()
 
 

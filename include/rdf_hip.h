@@ -223,6 +223,15 @@ int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
  * rdf_stream_destroy releases it. */
 int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved);
 int rdf_stream_destroy(void *stream);
+/* Peer-to-peer plumbing for the multi-GPU gather (no reference counterpart): a raw device allocation
+ * whose 64-byte IPC handle another process of the node opens to get a pointer it can copy into.  rdf_memcpy_device_async
+ * is hipMemcpyAsync(hipMemcpyDefault): device-to-device copies between GPUs run on the copy engines, not on CUs. */
+int rdf_device_malloc(void **ptr, size_t bytes);
+int rdf_device_free(void *ptr);
+int rdf_ipc_export(void *ptr, unsigned char handle_out[64]);
+int rdf_ipc_open(const unsigned char handle[64], void **ptr_out);
+int rdf_ipc_close(void *ptr);
+int rdf_memcpy_device_async(void *dst, const void *src, size_t bytes, void *stream);
 /* Test hook: n_workgroups workgroups with RCCL's send/recv kernel's footprint (256 threads, >250 VGPRs, 19.7 KB LDS) that
  * record their start time (wall_clock64 ticks, 100 MHz) in t_start[workgroup] and spin for spin_ticks. */
 int rdf_debug_fat_kernel(int n_workgroups, unsigned long long spin_ticks, unsigned long long *t_start, void *stream);

@@ -80,3 +80,61 @@ def test_shard_range_partitions_the_batch(rdf):
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(wsz - 1))
     assert dmod.shard_range(1024, 3, 8) == (384, 512)
+
+
+def _p2p_worker(rank, world, port, tmpdir):
+    """Two processes on the one GPU of the test box: rank 0 exports its receive buffer, rank 1 maps it through HIP
+    IPC, both copy their label maps in with hipMemcpyAsync on a side stream; gloo only carries the control plane."""
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    rdf = importlib.import_module("3d-beats_amd")
+    dmod = importlib.import_module("3d-beats_amd.distributed")
+    from oracle import rdf_oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames, h, w, r = 6, 120, 200, 2
+        forest_np = rdf.synth.forest(4, 9, 4, "trained")
+        forest = rdf.DecisionForest.from_numpy(forest_np)
+        mine = rdf.synth.mixed_batch(frames, first_idx=rank * frames, h=h, w=w)
+        ev = rdf.DecisionTreeEvaluator()
+        nbytes = frames * (h // r) * (w // r) * 2
+        gather = dmod.PeerCopyGather(world, rank, nbytes)
+        assert gather.ok, "HIP IPC between two processes on one GPU should work"
+        pe = dmod.PeerCopyForestEvaluator(ev, forest, frames, (h, w), gather, labels_reduce=r, scale_factor=0.5)
+        depth = rdf.to_device(mine)
+        ring = [rdf.DeviceArray((frames, h // r, w // r), np.uint16) for _ in range(2)]
+        for _ in range(5):
+            pe.step(depth, ring, prefill=65535)
+        pe.drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            got = pe.result().cpu().numpy().view(np.uint16)
+            assert got.shape == (world * frames, h // r, w // r)
+            for g in range(world):
+                fr = rdf.synth.mixed_batch(frames, first_idx=g * frames, h=h, w=w)
+                want = np.full((frames, h // r, w // r), 65535, np.uint16)
+                rdf_oracle.eval_forest(fr, forest_np, want, r, scale_factor=0.5)
+                assert np.array_equal(got[g * frames:(g + 1) * frames], want), f"shard {g}"
+            open(os.path.join(tmpdir, "ok"), "w").write("ok")
+        else:
+            assert pe.result() is None
+        dist.barrier()          # rank 0 is done reading before anyone unmaps
+        gather.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_process_peer_copy_gather_on_one_gpu(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    mp.spawn(_p2p_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
