@@ -14,7 +14,7 @@ def main(root):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = row.get("Kernel_Name", "?")
-                key = (k[:70], row.get("Grid_Size", "?"))
+                key = (k[:90], row.get("Grid_Size", "?"))
                 acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for key in sorted(acc):
         n = max(len(v) for v in acc[key].values())
