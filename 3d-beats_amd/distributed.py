@@ -136,7 +136,7 @@ class PeerCopyGather:
     `ok` is False on every rank if any rank could not map the buffer (no IPC between the processes, e.g. devices hidden
     from each other): callers then fall back to the RCCL gather."""
 
-    def __init__(self, world, rank, bytes_per_rank, dst=0, group=None):
+    def __init__(self, world, rank, bytes_per_rank, dst=0, group=None, _fail_open_on_rank=None):
         import torch
         import torch.distributed as dist
         self._lib = get_runtime().lib
@@ -164,6 +164,10 @@ class PeerCopyGather:
             else:
                 p = ctypes.c_void_p()
                 rc = self._lib.rdf_ipc_open(ctypes.create_string_buffer(handle[0], 64), ctypes.byref(p))
+                if _fail_open_on_rank == self.rank:       # test hook: behave as if this rank could not map the buffer
+                    if rc == 0:
+                        self._lib.rdf_ipc_close(p)
+                    rc = -1
                 if rc == 0:
                     self._mapped = p.value
                     self.base = self._mapped

@@ -106,6 +106,9 @@ def _p2p_worker(rank, world, port, tmpdir):
         mine = rdf.synth.mixed_batch(frames, first_idx=rank * frames, h=h, w=w)
         ev = rdf.DecisionTreeEvaluator()
         nbytes = frames * (h // r) * (w // r) * 2
+        # a rank that cannot map the buffer turns the mode off on EVERY rank (callers then use the RCCL gather)
+        broken = dmod.PeerCopyGather(world, rank, nbytes, _fail_open_on_rank=1)
+        assert not broken.ok and broken.base is None
         gather = dmod.PeerCopyGather(world, rank, nbytes)
         assert gather.ok, "HIP IPC between two processes on one GPU should work"
         pe = dmod.PeerCopyForestEvaluator(ev, forest, frames, (h, w), gather, labels_reduce=r, scale_factor=0.5)
