@@ -60,7 +60,9 @@ class HandPipeline:
     def capture(self, depth_image, depth_image_mm_groups, g_id, flip_x):
         """Records the chain for these buffers and arguments into a hipGraph (through torch) and returns a
         function that replays it on the buffers' current contents and returns what run() returns: one graph
-        launch per hand per frame instead of ~16 kernel launches."""
+        launch per hand per frame instead of ~16 kernel launches.  replay(read=False) only enqueues (replay.read()
+        fetches the result later), so the two hands of a frame -- two HandPipeline objects, each captured under its
+        own torch stream -- can be in flight together."""
         import torch
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):      # warm-up on the capture stream: workspaces, occupancy queries, queue slot
@@ -70,9 +72,10 @@ class HandPipeline:
         with torch.cuda.graph(graph, stream=side):
             self._enqueue(depth_image, depth_image_mm_groups, g_id, flip_x)
 
-        def replay():
+        def replay(read=True):
             graph.replay()
-            return self._read()
+            return self._read() if read else None
+        replay.read = self._read
         return replay
 
     def _read(self):

@@ -51,10 +51,39 @@ def main():
         replays[0]()
     torch.cuda.synchronize()
     dg = (time.perf_counter() - t0) / n
+    # both hands of a frame in flight together: two pipelines, two streams, two graphs
+    pipe2 = pl.HandPipeline(lf, (H, W), R, 1.0, 6, np.full(7, 40., np.float32), [3, 4, 5, 6, 7],
+                            (421.3, 420.9, 423.1, 238.6), np.eye(4, dtype=np.float32))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        r1 = pipe.capture(dbuf, gbuf, 1, False)
+    with torch.cuda.stream(s2):
+        r2 = pipe2.capture(dbuf, gbuf, 2, True)
+    torch.cuda.synchronize()
+
+    def both():
+        with torch.cuda.stream(s1):
+            r1(read=False)
+        with torch.cuda.stream(s2):
+            r2(read=False)
+        with torch.cuda.stream(s1):
+            a = r1.read()
+        with torch.cuda.stream(s2):
+            b = r2.read()
+        return a, b
+    for _ in range(20):
+        both()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        both()
+    torch.cuda.synchronize()
+    d2 = (time.perf_counter() - t0) / n
     print(json.dumps({"hand_pipeline": {"frame": [H, W], "labels_reduce": R, "layers": 2, "trees": 4, "tree_depth": 18,
                                         "mean_shift_rounds": 6, "us_per_hand_per_frame": round(dt * 1e6, 1),
                                         "us_per_hand_per_frame_as_hipgraph": round(dg * 1e6, 1),
-                                        "hands_per_second_as_hipgraph": round(1 / dg, 1)}}))
+                                        "hands_per_second_as_hipgraph": round(1 / dg, 1),
+                                        "us_per_frame_both_hands_two_streams": round(d2 * 1e6, 1)}}))
 
 
 if __name__ == "__main__":
