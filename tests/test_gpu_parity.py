@@ -447,3 +447,33 @@ def test_largest_batch_one_call_addresses(rdf, evs, oracle):
     assert not bool(torch.logical_and(l_t == -1, ~invalid).any())   # and every valid pixel did get a label
     del depth, labels, d_t, l_t, invalid
     torch.cuda.empty_cache()
+
+
+def test_cu_masked_stream_gives_the_same_labels(rdf, evs, oracle, gpu_runtime):
+    """The compute stream bench.py uses next to RCCL (one CU per shader engine left out): same results, and the
+    argument checks of the stream helper."""
+    import ctypes
+    import torch
+    lib = gpu_runtime.lib
+    h = ctypes.c_void_p()
+    assert lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), 0) == -1
+    assert lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), 100000) == -1
+    assert lib.rdf_stream_create_with_reserved_cus(None, 32) != 0
+    assert lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), 32) == 0
+    try:
+        forest_np = rdf.synth.forest(4, 12, 4, "trained", first_tree=33)
+        depth = rdf.synth.mixed_batch(6, first_idx=4321, h=240, w=424)
+        want = np.full(depth.shape, 65535, np.uint16)
+        oracle.eval_forest(depth, forest_np, want)
+        forest = rdf.DecisionForest.from_numpy(forest_np)
+        d_dev = rdf.to_device(depth)
+        out = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.ExternalStream(h.value)):
+            for _ in range(2):
+                evs["packed"].get_labels_forest(forest, d_dev, out)
+            got = out.get()
+        assert np.array_equal(got, want)
+    finally:
+        torch.cuda.synchronize()
+        assert lib.rdf_stream_destroy(h) == 0
