@@ -114,6 +114,7 @@ def load_traffic(key):
 
 def main():
     a = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL, peer-mapped buffers); before HIP starts
     import torch
     import torch.distributed as dist
 
