@@ -11,7 +11,8 @@ test_on_saved_model.py:54-56):
         .make_composite_labels_image                                        decision_tree.py:267-347
 
 Kernels are reached through the C ABI of librdf_hip.so (include/rdf_hip.h); launch geometry is the
-library's business.  The dataset/training half of the reference module is out of scope.
+library's business.  The trainer half of the reference module (decision_tree.py:353-600) is further down:
+make_random_features and DecisionTreeTrainer; the dataset reader lives in dataset.py.
 """
 import json
 import os
@@ -77,7 +78,8 @@ class DecisionForest:
         self._packed = {}  # scale_factor -> (forest_cu identity, version, DeviceArray)
 
     def packed(self, scale_factor=1.):
-        """32-byte-record table for `scale_factor`, rebuilt when forest_cu has been written since.
+        """Packed tables (16-byte hot records + 32-byte exact records) for `scale_factor`, rebuilt when forest_cu
+        has been written since.
 
         The reference has no such step (its load is the upload at decision_tree.py:148-158); this is
         the load-time repack described in include/rdf_hip.h.  Returns None for an empty forest."""
