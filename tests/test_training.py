@@ -185,3 +185,48 @@ def test_train_forest_flow_from_a_dataset_directory(rdf, gpu_runtime, tmp_path):
     assert pct > 0.5
     f = rdf.DecisionForest.load(str(out))
     assert (f.num_trees, f.max_depth, f.num_classes) == (2, 6, 4)
+
+
+@pytest.mark.gpu
+def test_device_trainer_fuzz_against_restatement(rdf, gpu_runtime):
+    """Seeded random training problems (image sizes that do not divide the 32x8 tiles, odd proposal counts, node
+    blocks, 2-6 classes, unlabelled and invalid-depth pixels): the trained tree must equal the restatement's bit for
+    bit.  RDF_TRAIN_FUZZ_ROUNDS / RDF_TRAIN_FUZZ_SEED for longer soaks."""
+    import os
+    dt = importlib.import_module("3d-beats_amd.decision_tree")
+    rounds = int(os.environ.get("RDF_TRAIN_FUZZ_ROUNDS", "4"))
+    rng = np.random.default_rng(int(os.environ.get("RDF_TRAIN_FUZZ_SEED", "4242")))
+    for it in range(rounds):
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(9, 70)), int(rng.integers(9, 90))
+        C, D = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+        P, blocks = int(rng.integers(1, 23)), int(rng.integers(1, 3))
+        max_nodes = int(rng.choice([1 << 17, 8, 4]))
+        depth = rdf.synth.frames([str(k) for k in rng.choice(["dense", "live"], size=n)], 9000 + it, h, w)
+        depth[rng.random(depth.shape) < 0.03] = 0
+        labels = rng.integers(0, C, size=depth.shape).astype(np.uint16)
+        if rng.random() < 0.5:                      # spatially coherent labels instead of noise
+            yy, xx = np.mgrid[0:h, 0:w]
+            labels[:] = (1 + ((xx * 3 // max(w, 1)) + (depth > 4000)) % (C - 1)).astype(np.uint16)
+        labels[rng.random(depth.shape) < 0.3] = 0   # unlabelled
+        if (labels > 0).sum() == 0:
+            labels[0, 0, 0] = 1
+        ds = _ArrayDataset(depth, labels, C, per_block=n)
+        trainer = rdf.DecisionTreeTrainer(n, P)
+        trainer.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK = max_nodes
+        trainer.allocate(ds, blocks * P, D)
+        tree = rdf.DecisionTree(D, C)
+        seed = int(rng.integers(0, 2 ** 31))
+        np.random.seed(seed)
+        trainer.train(ds, tree)
+        got = tree.tree_out_cu.get()
+
+        def proposals(k):
+            arr = np.zeros((k, 5), np.float32)
+            dt.make_random_features(k, arr)
+            return arr
+
+        np.random.seed(seed)
+        want = tn.train_tree(depth, labels, C, D, blocks, P, max_next_nodes_per_block=max_nodes, proposal_fn=proposals)
+        same = got.view(np.uint32) == want.view(np.uint32)
+        assert same.all(), (f"round {it}: n{n} {h}x{w} C{C} D{D} P{P}x{blocks} nodes/block {max_nodes}: "
+                            f"{(~same).sum()} words differ, first at {np.argwhere(~same)[:3].tolist()}")
