@@ -5,7 +5,8 @@ One "step" = one pass of the forest kernel over this rank's batch of synthetic 8
 (4 trees, depth 20, 4 classes -- BASELINE.json's metric config), frames already resident in HBM.
 Default workload: 128 frames per GPU per step (= config 4's shard, 1024 frames / 8 GPUs; it is
 config 2's frame x 128, half dense / half live-like), weak scaling: N GPUs evaluate N x 128 frames
-and rank 0 gathers all label maps (RCCL over xGMI) inside the timed region.  Config 2 itself
+and every rank's label maps reach rank 0 over xGMI inside the timed region (copy-engine peer copies into rank 0's
+IPC-mapped buffer by default, an RCCL gather as the fallback: DESIGN.md section 6).  Config 2 itself
 (ONE 848x480 frame per launch) is measured in the same run and reported as `cfg2_single_frame`.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
