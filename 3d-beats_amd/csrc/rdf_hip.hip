@@ -47,7 +47,7 @@ namespace {
 
 constexpr int kGroup = 4;          // trees walked interleaved by one lane (template GROUP: 1 and 2 for smaller forests)
 constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
-constexpr int kDefaultLdsBudget = 32000;   // node table + depth tile per workgroup
+constexpr int kDefaultLdsBudget = 32700;   // node table + depth tile per workgroup
 constexpr int kDefaultHalo = 24;   // depth pixels staged around a tile's centres
 constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
 constexpr int kSchedSlots = 256;
@@ -108,6 +108,7 @@ struct EvalArgs {
     int tw, th, twp;       // staged depth tile: width, height, row pitch (0: no staged tile)
     uint32_t lds_tile_off; // byte offsets inside the dynamic LDS allocation
     uint32_t lds_mail_off;
+    uint32_t lds_list_off;
     int filter_class;
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
     int fill_untouched;    // fused pre-fill: write 65535 to every label pixel that is not evaluated
@@ -189,13 +190,14 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
 
 // FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
 // a.rows_per_wave rows (latency shape for small launches such as one live frame).
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint4 *lds_nodes = reinterpret_cast<uint4 *>(lds_raw);
     uint16_t *lds_tile = reinterpret_cast<uint16_t *>(lds_raw + a.lds_tile_off);
     uint32_t *s_tile = reinterpret_cast<uint32_t *>(lds_raw + a.lds_mail_off);
+    uint16_t *px_list = reinterpret_cast<uint16_t *>(lds_raw + a.lds_list_off);   // the tile's pixels to evaluate, compacted
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -292,21 +294,79 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             __syncthreads();
         }
 
-        for (int sub = 0; sub < rows_per_wave; ++sub) {
+        // ---- compact the tile's pixels that have something to evaluate.  Live frames are mostly background and a
+        // filtered layer only looks at one class: with one fixed pixel per lane, waves along the edge of the hand
+        // ran mostly empty (a live-only batch reached 72 % of the dense rate per valid pixel).  The pixels that
+        // pass the early-outs of tree_eval.cu:81-89 are listed in row-major order and dealt to the waves 64 at a
+        // time, so a wave is idle only in the tile's last partial group.  Pixels that do not pass are left
+        // untouched -- unless the caller asked for the fused pre-fill, which stores what its fill(65535) would. ----
+        // COMPACT is instantiated for filtered launches only: without a filter the memory pipeline, which idle lanes
+        // do not load, is the limit (a live-only batch did not get faster) and the two extra barriers cost a single
+        // dense frame 8 % (measured); then lane = column, as the list would have it for a full tile, and the early-outs
+        // are taken in the loop below.
+        constexpr bool compact = COMPACT;
+        uint32_t *s_cnt = reinterpret_cast<uint32_t *>(px_list + BLOCK * rows_per_wave);   // valid pixels per tile row
+        uint32_t my_rank[kMaxRowsPerWave];
+        uint32_t my_valid = 0u;
+#pragma unroll
+        for (int sub = 0; sub < kMaxRowsPerWave; ++sub) {
+            if (sub >= rows_per_wave || !compact) break;
             // rows of the workgroup's waves are interleaved: at any time they cover adjacent rows
             const int ly = (int)(ty * tile_rows + (uint32_t)sub * kWaves + wave);
-            if (ly >= a.Hl || lx >= a.Wl) continue;
-            const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
-            const int x = lx * a.r, y = ly * a.r;
+            bool ok = ly < a.Hl && lx < a.Wl;
+            if (ok) {
+                const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
+                if (a.filter_class != -1) ok = (int)a.filter[i] == a.filter_class;
+                if (ok) {
+                    const uint32_t d = (uint32_t)probe_value(probe_issue(pc, lx * a.r - tx0, ly * a.r - ty0));
+                    ok = d != 0u && d != kNoPixel;
+                }
+                if (!ok && a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
+            }
+            const unsigned long long b = __ballot(ok);
+            if (lane == 0) s_cnt[(uint32_t)sub * kWaves + wave] = (uint32_t)__popcll(b);
+            my_rank[sub] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            my_valid |= ok ? 1u << sub : 0u;
+        }
+        uint32_t n_valid = BLOCK * (uint32_t)rows_per_wave;
+        if (compact) {
+            __syncthreads();
+            n_valid = 0u;
+            uint32_t my_base[kMaxRowsPerWave];
+            for (uint32_t row = 0; row < tile_rows; ++row) {   // (LDS broadcast reads; tile_rows <= 64)
+#pragma unroll
+                for (int sub = 0; sub < kMaxRowsPerWave; ++sub)
+                    if (row == (uint32_t)sub * kWaves + wave) my_base[sub] = n_valid;
+                n_valid += s_cnt[row];
+            }
+#pragma unroll
+            for (int sub = 0; sub < kMaxRowsPerWave; ++sub) {
+                if (sub >= rows_per_wave) break;
+                if ((my_valid >> sub) & 1u)
+                    px_list[my_base[sub] + my_rank[sub]] = (uint16_t)((((uint32_t)sub * kWaves + wave) << 6) | (uint32_t)lane);
+            }
+            __syncthreads();
+        }
 
-            // Pixels the reference kernel returns early on are left untouched (tree_eval.cu:81-89) -- unless the
-            // caller asked for the fused pre-fill, which stores what its separate fill(65535) would have left.
-            bool skip = false;
-            if (a.filter_class != -1) skip = (int)a.filter[i] != a.filter_class;
-            uint32_t d = 0u;
+        for (uint32_t first = wave * 64u; first < n_valid; first += BLOCK) {
+            // uncompacted: pass `first / BLOCK` over the wave's own rows (rows of the workgroup's waves are interleaved)
+            uint32_t entry = (((first / BLOCK) * kWaves + wave) << 6) | (uint32_t)lane;
+            if (compact) {
+                if (first + (uint32_t)lane >= n_valid) continue;
+                entry = px_list[first + (uint32_t)lane];
+            }
+            const int ly = (int)(ty * tile_rows + (entry >> 6));
+            const int px = (int)(tx * 64u + (entry & 63u));
+            if (!compact && (ly >= a.Hl || px >= a.Wl)) continue;
+            const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)px;
+            const int x = px * a.r, y = ly * a.r;
             const int xl = x - tx0, yl = y - ty0;   // this pixel, relative to the staged tile
+            // tree_eval.cu:81-89 (a listed pixel passed these already)
+            bool skip = false;
+            if (!compact && a.filter_class != -1) skip = (int)a.filter[i] != a.filter_class;
+            uint32_t d = 0u;
             if (!skip) d = (uint32_t)probe_value(probe_issue(pc, xl, yl));
-            if (skip || d == 0u || d == kNoPixel) {
+            if (!compact && (skip || d == 0u || d == kNoPixel)) {
                 if (a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
                 continue;
             }
@@ -706,10 +766,23 @@ struct LaunchGeom {
 };
 std::map<std::tuple<int, const void *, int>, int> g_occ_cache;   // (device, kernel, LDS bytes) -> workgroups per CU
 
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
+int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st);
+
+// Filtered launches (a layer that only looks at one class of an earlier layer) list the pixels to evaluate first and
+// deal them to the waves 64 at a time (COMPACT); these exist for the default workgroup size only.
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
 int launch_group(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP>;
+    if (BLOCK == 256 && !STATS && a.filter_class != -1)   // == compact_launch in eval_common, which sized the LDS for it
+        return launch_compact<256, PACKED, CMAX, false, FULLROWS, GROUP, true>(a, lds_bytes, cus, st);
+    return launch_compact<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP, false>(a, lds_bytes, cus, st);
+}
+
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
+int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+{
+    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP, COMPACT>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
@@ -849,9 +922,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
 
-    // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B] ----
+    // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B][pixel list] ----
     const long long budget = lds_budget();
-    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", kDefaultHalo);
+    // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>): two pixels
+    // less halo keep five workgroups per CU
+    const bool compact_launch = block == 256 && !stats && filter_class != -1;
+    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", compact_launch ? kDefaultHalo - 2 : kDefaultHalo);
     long long tile_bytes = 0;
     if (halo >= 0) {
         const long long tw = 63ll * r + 1 + 2ll * halo;
@@ -864,13 +940,16 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
             tile_bytes = 0;   // tile does not fit (large labels_reduce): every probe reads global memory
         }
     }
+    // pixel list: one uint16 per tile pixel, then one uint32 per tile row
+    const long long list_bytes = compact_launch ? (((long long)block * rpw * 2 + (long long)tile_rows * 4) + 15) & ~15ll : 0;
     int K = 0;
-    while (K < max_depth && (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 32 <= budget) ++K;
+    while (K < max_depth && (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 32 + list_bytes <= budget) ++K;
     a.lds_levels = K;
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
     a.lds_tile_off = (uint32_t)(node_bytes + 16);
     a.lds_mail_off = (uint32_t)(node_bytes + 16 + tile_bytes);
-    const int lds_bytes = (int)(node_bytes + tile_bytes + 32);
+    a.lds_list_off = (uint32_t)(node_bytes + 32 + tile_bytes);
+    const int lds_bytes = (int)(node_bytes + tile_bytes + 32 + list_bytes);
 
     a.sched = sched_slot(stream);
 

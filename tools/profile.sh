@@ -20,6 +20,6 @@ for spec in fetch:"FETCH_SIZE TCC_HIT_sum" write:"WRITE_SIZE TCC_MISS_sum TCC_RE
 done
 cd $R && python3 tools/pmc_summary.py gpurun_out/$TAG > $O/summary.txt 2>&1
 head -12 $O/kernel_stats.csv
-grep -A16 "k_eval_forest<256, true, 4, false, true, 4>" $O/summary.txt | head -20
-python3 tools/make_traffic_json.py $O/summary.txt "F128_T4_D20_C4_full" "k_eval_forest<256, true, 4, false, true, 4>" > $O/roofline_traffic.json
+grep -A16 "k_eval_forest<256, true, 4, false, true, 4, false>" $O/summary.txt | head -20
+python3 tools/make_traffic_json.py $O/summary.txt "F128_T4_D20_C4_full" "k_eval_forest<256, true, 4, false, true, 4, false>" > $O/roofline_traffic.json
 cat $O/roofline_traffic.json
