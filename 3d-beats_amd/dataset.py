@@ -150,13 +150,21 @@ def evaluate_saved_model(model_path, dataset_dir, num_images, out_dir=None):
 
 
 def train_forest(dataset_dir, num_train, num_test, proposals, proposals_block, out_trees, max_depth, out_path=None,
-                 trees_to_try=None, train_block=None, log=print):
+                 trees_to_try=None, train_block=None, log=print, tree_seed=None, group=None):
     """The flow of src/train_model.py:52-139 without its GLFW window: train `trees_to_try` candidate trees, keep
-    the `out_trees` best by test accuracy, evaluate the forest, save it as the reference's .npy."""
+    the `out_trees` best by test accuracy, evaluate the forest, save it as the reference's .npy.
+
+    tree_seed (not in the reference): candidate tree i draws its proposals from numpy.random.seed(tree_seed + i)
+    instead of continuing the global stream.  That makes the candidates independent of each other, which is what
+    lets them be trained on different GPUs: with torch.distributed initialised (one process per GPU), rank r trains
+    candidates r, r + world, ...; the trees and their scores are exchanged with all_gather_object and every rank
+    keeps the same best ones -- the same forest, bit for bit, as one process with the same tree_seed."""
     from .decision_tree import DecisionForest, DecisionTree, DecisionTreeEvaluator, DecisionTreeTrainer
     from .device import DeviceArray
     from .util import MAX_UINT16
     trees_to_try = trees_to_try or out_trees
+    if tree_seed is not None:
+        np.random.seed(int(tree_seed))     # the random train/test split: the same in every process
     train_data, test_data = DecisionTreeDatasetConfig.multiple(dataset_dir, [(num_train, train_block, 'train'),
                                                                              (num_test, None, 'test')])
     trainer = DecisionTreeTrainer(train_block or num_train, proposals_block)
@@ -170,12 +178,27 @@ def train_forest(dataset_dir, num_train, num_test, proposals, proposals_block, o
     truth = test_labels.get()
     best = [None] * out_trees
     forest_cpu = np.zeros((out_trees, tree1.TOTAL_TREE_NODES, tree1.TREE_NODE_ELS), dtype=np.float32)
-    for i in range(trees_to_try):
+    rank, world = 0, 1
+    if tree_seed is not None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+    candidates = {}
+    for i in range(rank, trees_to_try, world):
+        if tree_seed is not None:
+            np.random.seed(int(tree_seed) + i)
         trainer.train(train_data, tree1)
         out_cu.fill(MAX_UINT16)
         evaluator.get_labels(tree1, test_depth, out_cu)
         pct = float(np.sum(out_cu.get() == truth) / np.sum(truth > 0))
         log(f'tree {i}: pct. matching pixels: {pct:.4f}')
+        candidates[i] = (pct, tree1.tree_out_cu.get())
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, candidates, group=group)
+        candidates = {i: v for part in parts for i, v in part.items()}
+    for i in range(trees_to_try):        # the reference's selection, in candidate order
+        pct, tree_np = candidates[i]
         slot = -1
         if None in best:
             slot = best.index(None)
@@ -183,7 +206,7 @@ def train_forest(dataset_dir, num_train, num_test, proposals, proposals_block, o
             slot = best.index(min(best))
         if slot > -1:
             best[slot] = pct
-            forest_cpu[slot] = tree1.tree_out_cu.get()
+            forest_cpu[slot] = tree_np
     forest = DecisionForest(out_trees, max_depth, test_data.num_classes())
     forest.forest_cu.set(forest_cpu)
     out_cu.fill(MAX_UINT16)

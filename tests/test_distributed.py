@@ -141,3 +141,46 @@ def test_two_process_peer_copy_gather_on_one_gpu(tmp_path, oracle):
     import torch.multiprocessing as mp
     mp.spawn(_p2p_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _train_worker(rank, world, port, tmpdir):
+    """Two processes on the one GPU train the candidate trees of a forest between them."""
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    importlib.import_module("3d-beats_amd")
+    ds_mod = importlib.import_module("3d-beats_amd.dataset")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        forest, pct = ds_mod.train_forest(os.path.join(tmpdir, "data"), 6, 4, 32, 16, 2, 6, None, trees_to_try=5,
+                                          log=lambda *_: None, tree_seed=1234)
+        np.save(os.path.join(tmpdir, f"forest_rank{rank}.npy"), forest)
+        open(os.path.join(tmpdir, f"pct_rank{rank}.txt"), "w").write(repr(pct))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_candidate_trees_trained_by_two_processes_give_the_single_process_forest(rdf, gpu_runtime, tmp_path):
+    import torch.multiprocessing as mp
+    from test_training import make_data
+    ds_mod = importlib.import_module("3d-beats_amd.dataset")
+    depth, labels = make_data(rdf, n=10, h=48, w=64, first=300)
+    ds_mod.write_dataset(str(tmp_path / "data"), depth, labels, {1: [255, 0, 0, 255], 2: [0, 255, 0, 255], 3: [0, 0, 255, 255]})
+    want, want_pct = ds_mod.train_forest(str(tmp_path / "data"), 6, 4, 32, 16, 2, 6, None, trees_to_try=5,
+                                         log=lambda *_: None, tree_seed=1234)
+    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"forest_rank{r}.npy")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"rank {r}"
+        assert eval(open(tmp_path / f"pct_rank{r}.txt").read()) == want_pct
+    # and tree_seed really decouples the candidates: a different seed gives a different forest
+    other, _ = ds_mod.train_forest(str(tmp_path / "data"), 6, 4, 32, 16, 2, 6, None, trees_to_try=5,
+                                   log=lambda *_: None, tree_seed=99)
+    assert not np.array_equal(other, want)
