@@ -41,6 +41,13 @@ constexpr int kTH = kRows + 2 * kHalo;        // staged tile rows
 constexpr int kMaxClasses = 64;
 constexpr int kBatch = 4;                     // proposals evaluated together: 8 probes in flight per lane
 
+// Tile queue of the histogram kernel: {next tile, workgroups finished}.  Zero at rest: the last workgroup of a launch
+// puts it back, so launches need no memset.  One queue per device: histogram launches of one device must not overlap
+// (the trainer issues them on one stream).  Labelled pixels cluster (a hand covers ~15 % of a frame), so tiles handed
+// out by static striding left the average SIMD with ONE resident wave while the unluckiest workgroup finished
+// (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE, level 0: 3.2 ms against a 1.4 ms VALU floor).
+__device__ unsigned int g_train_queue[2];
+
 // ---- root counts + nodes_by_pixel initialisation (decision_tree.py:452-468, done on the host there) ----
 __global__ __launch_bounds__(256) void k_train_init(const uint16_t *labels, size_t n_px, int C, int32_t *nodes, u64 *root)
 {
@@ -92,7 +99,13 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
     const bool all_fast = __syncthreads_and(mine_ok ? 1 : 0) != 0;
 
     const int j0 = 0, j1 = a.P;
-    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    __shared__ uint32_t s_next;
+    for (;;) {
+        if (tid == 0) s_next = atomicAdd(&g_train_queue[0], 1u);
+        __syncthreads();
+        const uint32_t tile = s_next;
+        __syncthreads();   // (s_next is rewritten in the next round)
+        if (tile >= a.n_tiles) break;
         const uint32_t per = a.tiles_x * a.tiles_y;
         const uint32_t img = tile / per, rem = tile - img * per;
         const uint32_t ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -211,6 +224,13 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
                     atomicAdd(a.counts + (size_t)j * a.NB * a.C + bin, (u64)n);
                 }
             }
+        }
+    }
+    if (tid == 0) {   // every workgroup has made its final, failing pull before it gets here
+        const unsigned int done = atomicAdd(&g_train_queue[1], 1u);
+        if (done == gridDim.x - 1u) {
+            atomicExch(&g_train_queue[0], 0u);
+            atomicExch(&g_train_queue[1], 0u);
         }
     }
 }
