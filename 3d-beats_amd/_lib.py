@@ -43,7 +43,7 @@ SIGNATURES = {
                                           _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "rdf_train_histogram_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "rdf_train_histogram_left_ws": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
-                                             _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+                                             _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_train_right_counts": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                         _c_void_p]),
     "rdf_train_pick_best": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

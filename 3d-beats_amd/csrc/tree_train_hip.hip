@@ -9,7 +9,8 @@
 //   * a wave covers an 8x8 block of pixels and counts with ballots and popcounts: one atomic per
 //     (node, class) group the block touches instead of one per pixel -- and, on the fast path
 //     (rdf_train_histogram_left_ws), only for the left children (the right ones follow from the
-//     parents) and for two proposals at a time (32-bit halves of one 64-bit word).  The rate of
+//     parents) and for two proposals at a time (32-bit halves of one 64-bit word), four where the
+//     (node, class) holds at most 65535 pixels (16-bit fields).  The rate of
 //     scattered global atomics (24e9/s, tools/ubench_atomic.hip) is what bounds this kernel;
 //   * the next level's node list is built by an ordered scan (the reference appends with an atomic
 //     counter, i.e. in scheduler order), so the whole training run is reproducible bit for bit;
@@ -71,8 +72,10 @@ struct HistArgs {
     uint32_t n_tiles, tiles_x, tiles_y;
     int W, H, P, C, NB, node_start, node_end;
     int left_only;   // count the left children only (the right ones follow from the parents, k_train_right_counts)
-    uint32_t *tmp;   // PAIRS: 32-bit counters [pair][bin][2], two proposals per 64-bit atomic (k_train_unpack_pairs)
+    uint32_t *tmp;   // PAIRS: 32-bit counters [pair][bin][2], two proposals per 64-bit atomic (k_train_unpack_pairs),
+                     // followed by 16-bit counters [quad][bin][4], four proposals per atomic (k_train_unpack_quads)
     int Ppad;
+    const u64 *parent_counts;   // [node][class] of the live pixels, or null: which bins may use 16-bit counters
 };
 
 // evaluate_random_features (tree_train.cu:4-64).
@@ -161,6 +164,9 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
             todo &= ~m;
         }
         const int bin0 = (node * 2 - a.node_start) * a.C + (int)label;   // left child's bin; right child's is + C
+        // a (node, class) with at most 65535 pixels can count four proposals in the 16-bit fields of one word
+        const bool small = PAIRS && a.parent_counts != nullptr && live &&
+                           a.parent_counts[(size_t)node * a.C + label] <= 65535ull;
 
         const ProbeCtx pc = {s_tile, reinterpret_cast<const char *>(a.depth) + img_off * 2, tx0, ty0, kTW, kTH, kTW,
                              a.W, a.H};
@@ -201,11 +207,18 @@ __global__ __launch_bounds__(256) void k_train_histogram(const HistArgs a)
                 if (live && lane == __ffsll((long long)peers) - 1) {
                     // tmp[pair][bin][2]: like the reference's [proposal][bin] layout, a bin's pairs lie far apart, so the
                     // adds of one bin spread over the L2 channels (a [bin][proposal] layout ran 2x slower)
-                    u64 *cell = reinterpret_cast<u64 *>(a.tmp) + (size_t)(jb >> 1) * a.NB * a.C + bin0;
+                    const size_t nbc = (size_t)a.NB * a.C;
+                    if (small) {
+                        static_assert(kBatch == 4, "one quad per batch");
+                        const u64 v = (u64)n[0] | ((u64)n[1] << 16) | ((u64)n[2] << 32) | ((u64)n[3] << 48);
+                        if (v) atomicAdd(reinterpret_cast<u64 *>(a.tmp) + (size_t)(a.Ppad >> 1) * nbc + (size_t)(jb >> 2) * nbc + bin0, v);
+                    } else {
+                        u64 *cell = reinterpret_cast<u64 *>(a.tmp) + (size_t)(jb >> 1) * nbc + bin0;
 #pragma unroll
-                    for (int k = 0; k < kBatch; k += 2) {
-                        const u64 v = (u64)n[k] | ((u64)n[k + 1] << 32);
-                        if (v) atomicAdd(cell + (size_t)(k >> 1) * a.NB * a.C, v);
+                        for (int k = 0; k < kBatch; k += 2) {
+                            const u64 v = (u64)n[k] | ((u64)n[k + 1] << 32);
+                            if (v) atomicAdd(cell + (size_t)(k >> 1) * nbc, v);
+                        }
                     }
                 }
                 continue;
@@ -248,6 +261,23 @@ __global__ __launch_bounds__(256) void k_train_unpack_pairs(uint32_t *tmp, int n
     *cell = 0u;
     const int j = pair * 2 + half;
     if (j < P) counts[(size_t)j * NB * C + bin] += v;
+}
+
+// the 16-bit part of the workspace: quads[quad][bin] (one 64-bit word = proposals 4q .. 4q+3) -> counts[j][bin]
+__global__ __launch_bounds__(256) void k_train_unpack_quads(u64 *quads, int n_bins, int P, int Ppad, int NB, int C, u64 *counts)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // (quad, bin), bins < n_bins only
+    if (t >= (long long)(Ppad / 4) * n_bins) return;
+    const int bin = (int)(t % n_bins), quad = (int)(t / n_bins);
+    u64 *cell = quads + (size_t)quad * NB * C + bin;
+    const u64 v = *cell;
+    if (!v) return;
+    *cell = 0ull;
+    for (int f = 0; f < 4; ++f) {
+        const u64 c = (v >> (16 * f)) & 0xFFFFull;
+        const int j = quad * 4 + f;
+        if (c && j < P) counts[(size_t)j * NB * C + bin] += c;
+    }
 }
 
 // Right-child counts from the parents: every live pixel of a node goes either left or right, so
@@ -452,7 +482,7 @@ static int pairs_ppad(int n_proposals) { return (n_proposals + kBatch - 1) / kBa
 static int train_histogram(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
                            int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes, int node_start,
                            int node_end, int nodes_per_block, unsigned long long *counts, int left_only, void *workspace,
-                           void *stream)
+                           const unsigned long long *parent_counts, void *stream)
 {
     if (n_img < 0 || dim_x < 0 || dim_y < 0 || n_proposals < 0 || n_classes < 1 || n_classes > kMaxClasses ||
         nodes_per_block < 1 || node_end - node_start > nodes_per_block || node_start < 0)
@@ -467,6 +497,7 @@ static int train_histogram(const uint16_t *depth, const uint16_t *labels, const 
     a.left_only = left_only;
     a.tmp = reinterpret_cast<uint32_t *>(workspace);
     a.Ppad = pairs_ppad(n_proposals);
+    a.parent_counts = parent_counts;
     a.tiles_x = (uint32_t)(dim_x + kCols - 1) / kCols;
     a.tiles_y = (uint32_t)(dim_y + kRows - 1) / kRows;
     const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
@@ -491,6 +522,13 @@ static int train_histogram(const uint16_t *depth, const uint16_t *labels, const 
         hipLaunchKernelGGL(k_train_unpack_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.tmp, n_bins, n_proposals,
                            a.Ppad, nodes_per_block, n_classes, counts);
         e = hipGetLastError();
+        if (e == hipSuccess && parent_counts) {
+            u64 *quads = reinterpret_cast<u64 *>(a.tmp) + (size_t)(a.Ppad / 2) * nodes_per_block * n_classes;
+            const long long nq = (long long)n_bins * (a.Ppad / 4);
+            hipLaunchKernelGGL(k_train_unpack_quads, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, quads, n_bins,
+                               n_proposals, a.Ppad, nodes_per_block, n_classes, counts);
+            e = hipGetLastError();
+        }
     }
     return (int)e;
 }
@@ -500,7 +538,7 @@ int rdf_train_histogram(const uint16_t *depth, const uint16_t *labels, const int
                         int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
 {
     return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
-                           node_start, node_end, nodes_per_block, counts, 0, nullptr, stream);
+                           node_start, node_end, nodes_per_block, counts, 0, nullptr, nullptr, stream);
 }
 
 int rdf_train_histogram_left(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
@@ -508,23 +546,24 @@ int rdf_train_histogram_left(const uint16_t *depth, const uint16_t *labels, cons
                              int node_start, int node_end, int nodes_per_block, unsigned long long *counts, void *stream)
 {
     return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
-                           node_start, node_end, nodes_per_block, counts, 1, nullptr, stream);
+                           node_start, node_end, nodes_per_block, counts, 1, nullptr, nullptr, stream);
 }
 
 size_t rdf_train_histogram_workspace_bytes(int n_proposals, int nodes_per_block, int n_classes)
 {
     if (n_proposals < 0 || nodes_per_block < 0 || n_classes < 0) return 0;
-    return (size_t)nodes_per_block * (size_t)n_classes * (size_t)pairs_ppad(n_proposals) * sizeof(uint32_t);
+    // 32-bit pair counters (4 bytes per bin and proposal) + 16-bit quad counters (2 bytes)
+    return (size_t)nodes_per_block * (size_t)n_classes * (size_t)pairs_ppad(n_proposals) * 6u;
 }
 
 int rdf_train_histogram_left_ws(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
                                 int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
                                 int node_start, int node_end, int nodes_per_block, unsigned long long *counts,
-                                void *workspace, void *stream)
+                                void *workspace, const unsigned long long *parent_counts, void *stream)
 {
     if (!workspace) return RDF_ERR_NULL_PTR;
     return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
-                           node_start, node_end, nodes_per_block, counts, 1, workspace, stream);
+                           node_start, node_end, nodes_per_block, counts, 1, workspace, parent_counts, stream);
 }
 
 int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,

@@ -438,7 +438,7 @@ class DecisionTreeTrainer:
                                                         n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
                                                         node_block_start, node_block_end, NB,
                                                         self.current_next_node_counts_by_feature_cu_block.ptr,
-                                                        self._hist_workspace.ptr, st()),
+                                                        self._hist_workspace.ptr, self.node_counts_cu.ptr, st()),
                         "rdf_train_histogram_left_ws")
                     chk(lib.rdf_train_right_counts(num_active_nodes, self.active_nodes_cu.ptr, P, NB, node_block_start,
                                                    node_block_end, C, self.node_counts_cu.ptr,

@@ -178,8 +178,9 @@ int rdf_make_rgba_from_labels(int dim_x, int dim_y, int num_colors, const uint16
  * rdf_train_histogram_left  the same, but only the LEFT children are counted (half the atomics, which bound the kernel);
  * rdf_train_histogram_left_ws  the same result as rdf_train_histogram_left, faster: it counts into a caller-owned
  *                           workspace of rdf_train_histogram_workspace_bytes() bytes (8-byte aligned, ZERO before the first
- *                           call; every call leaves it zero) where one 64-bit atomic serves two proposals, then adds
- *                           the workspace into `counts`
+ *                           call; every call leaves it zero) where one 64-bit atomic serves two proposals -- or four, for a
+ *                           (node, class) with at most 65535 pixels according to parent_counts ([node][class] counts of the
+ *                           live pixels, as kept by the trainer; may be NULL) -- then adds the workspace into `counts`
  * rdf_train_right_counts    then fills counts[j][right][c] = parent_counts[node][c] - counts[j][left][c] for the children of
  *                           the active nodes that fall in [node_start, node_end).  Call it once, after every image has
  *                           been counted; the pair leaves `counts` exactly as rdf_train_histogram does
@@ -201,7 +202,7 @@ size_t rdf_train_histogram_workspace_bytes(int n_proposals, int nodes_per_block,
 int rdf_train_histogram_left_ws(const uint16_t *depth, const uint16_t *labels, const int32_t *nodes_by_pixel, int n_img,
                                 int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
                                 int node_start, int node_end, int nodes_per_block, unsigned long long *counts,
-                                void *workspace, void *stream);
+                                void *workspace, const unsigned long long *parent_counts, void *stream);
 int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,
                            int node_start, int node_end, int n_classes, const unsigned long long *parent_counts,
                            unsigned long long *counts, void *stream);

@@ -93,6 +93,44 @@ def test_device_trainer_matches_restatement_bit_for_bit(cfg, rdf, gpu_runtime):
 
 
 @pytest.mark.gpu
+def test_histogram_variants_agree_when_big_and_small_bins_mix(rdf, gpu_runtime):
+    """At one level, (node, class) bins above 65535 pixels (32-bit pair counters) next to bins below (16-bit quad
+    counters): the workspace variant must still equal the plain one-atomic-per-group kernel."""
+    dt = importlib.import_module("3d-beats_amd.decision_tree")
+    n, h, w, C, D, P = 6, 240, 424, 4, 3, 37
+    depth = rdf.synth.frames(["dense"] * n, 7100, h, w)
+    rng = np.random.default_rng(3)
+    labels = np.where(rng.random(depth.shape) < 0.9, 1, rng.integers(2, C, size=depth.shape)).astype(np.uint16)
+    ds = _ArrayDataset(depth, labels, C, per_block=n)
+    trainer = rdf.DecisionTreeTrainer(n, P)
+    trainer.allocate(ds, P, D)
+    tree = rdf.DecisionTree(D, C)
+    np.random.seed(21)
+    trainer.train(ds, tree)
+    lib, st = gpu_runtime.lib, gpu_runtime.stream
+    parents = trainer.node_counts_cu.get().reshape(-1, C)
+    nodes_px = trainer.nodes_by_pixel_cu.get()
+    live_nodes = np.unique(nodes_px[nodes_px >= 0])
+    sizes = parents[live_nodes]
+    assert (sizes > 65535).any() and ((sizes > 0) & (sizes <= 65535)).any(), sizes
+    props = np.zeros((P, 5), np.float32)
+    np.random.seed(8)
+    dt.make_random_features(P, props)
+    d_props = rdf.to_device(props)
+    NB = trainer.nodes_per_block
+    args = (trainer.depth_cu.ptr, trainer.labels_cu.ptr, trainer.nodes_by_pixel_cu.ptr, n, w, h, d_props.ptr, P, C, 0, 1 << D, NB)
+    plain = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
+    assert lib.rdf_train_histogram_left(*args, plain.ptr, st()) == 0
+    ws = rdf.DeviceArray((int(lib.rdf_train_histogram_workspace_bytes(P, NB, C)),), np.uint8).fill(0)
+    for parents_ptr in (trainer.node_counts_cu.ptr, None):
+        fast = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
+        assert lib.rdf_train_histogram_left_ws(*args, fast.ptr, ws.ptr, parents_ptr, st()) == 0
+        assert np.array_equal(fast.get(), plain.get())
+        assert not ws.get().any()
+    assert plain.get().sum() > 0
+
+
+@pytest.mark.gpu
 def test_left_only_histogram_plus_right_counts_equals_full_histogram(rdf, gpu_runtime):
     """rdf_train_histogram_left + rdf_train_right_counts must leave the count array exactly as the one-call
     rdf_train_histogram (= evaluate_random_features) does, here on the last level of a trained tree (many nodes)."""
@@ -133,12 +171,14 @@ def test_left_only_histogram_plus_right_counts_equals_full_histogram(rdf, gpu_ru
                                       split.ptr, st()) == 0
     # ... and the workspace variant (two proposals per 64-bit atomic) leaves the same left counts and a zero workspace
     ws_bytes = int(lib.rdf_train_histogram_workspace_bytes(P, NB, C))
-    assert ws_bytes == NB * C * ((P + 3) // 4 * 4) * 4
+    assert ws_bytes == NB * C * ((P + 3) // 4 * 4) * 6
     ws = rdf.DeviceArray((ws_bytes,), np.uint8).fill(0)
     packed = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
-    for _ in range(2):   # twice: the second call relies on the first one having cleaned up
+    for parents in (None, trainer.node_counts_cu.ptr, None, trainer.node_counts_cu.ptr):
+        # twice each: a call relies on the previous one having cleaned up; with the parents' counts the small
+        # (node, class) bins -- all of them in this little problem -- count four proposals per 64-bit word
         packed.fill(0)
-        assert lib.rdf_train_histogram_left_ws(*args, packed.ptr, ws.ptr, st()) == 0
+        assert lib.rdf_train_histogram_left_ws(*args, packed.ptr, ws.ptr, parents, st()) == 0
         assert np.array_equal(packed.get(), left_only)
         assert not ws.get().any()
     want, got = full.get(), split.get()
