@@ -43,7 +43,7 @@ constexpr int kMaxClasses = 64;
 constexpr int kBatch = 4;                     // proposals evaluated together: 8 probes in flight per lane
 
 // Tile queue of the histogram kernel: {next tile, workgroups finished}.  Zero at rest: the last workgroup of a launch
-// puts it back, so launches need no memset.  One queue per device: histogram launches of one device must not overlap
+// puts it back (the host clears it before every launch all the same).  One queue per device: histogram launches of one device must not overlap
 // (the trainer issues them on one stream).  Labelled pixels cluster (a hand covers ~15 % of a frame), so tiles handed
 // out by static striding left the average SIMD with ONE resident wave while the unluckiest workgroup finished
 // (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE, level 0: 3.2 ms against a 1.4 ms VALU floor).
@@ -508,6 +508,13 @@ static int train_histogram(const uint16_t *depth, const uint16_t *labels, const 
     long long grid = (long long)cus * 8;
     if (grid > n_tiles) grid = n_tiles;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    {   // the kernel leaves its tile queue at zero; clearing it here as well keeps a launch that died half-way from
+        // silently shortening the next one
+        void *q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_train_queue)) != hipSuccess || !q) return RDF_ERR_NO_DEVICE;
+        const hipError_t eq = hipMemsetAsync(q, 0, sizeof(unsigned int) * 2, st);
+        if (eq != hipSuccess) return (int)eq;
+    }
     if (!workspace) {
         hipLaunchKernelGGL(k_train_histogram<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
         return (int)hipGetLastError();
