@@ -281,6 +281,27 @@ def main():
     }
 
     if rank == 0 and world == 1 and not a.headline_only:
+        # ---- what HBM really delivers to a plain stream: a 1-GB device-to-device copy (SURVEY 8d asks for the roofline
+        # against the spec peak AND a measured copy ceiling) ----
+        src_t = torch.empty(1 << 30, dtype=torch.uint8, device="cuda").fill_(1)
+        dst_t = torch.empty_like(src_t)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for _ in range(4):
+            c0.record()
+            dst_t.copy_(src_t)
+            c1.record()
+            torch.cuda.synchronize()
+            ms = c0.elapsed_time(c1)
+            best = ms if best is None else min(best, ms)
+        ceiling = 2.0 * (1 << 30) / (best * 1e-3) / 1e9      # bytes read + bytes written
+        out["roofline"]["copy_ceiling"] = {"value": round(ceiling, 1), "unit": "GB/s",
+                                           "frac_of_ceiling": round(achieved / ceiling, 4),
+                                           "hbm_traffic_gbs": (round(out["roofline"]["traffic"] / kern_avg_s / 1e9, 1)
+                                                               if out["roofline"]["traffic"] else None),
+                                           "what": "1-GB device-to-device copy, read + written bytes per second"}
+        del src_t, dst_t
+
         # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
         one_d, one_l = depth[0:1], rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
         for _ in range(10):
