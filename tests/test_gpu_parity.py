@@ -478,3 +478,41 @@ def test_cu_masked_stream_gives_the_same_labels(rdf, evs, oracle, gpu_runtime):
     finally:
         torch.cuda.synchronize()
         assert lib.rdf_stream_destroy(h) == 0
+
+
+@pytest.mark.parametrize("r,s", [(1, 1.0), (3, 0.5)])
+def test_three_layer_stack_matches_oracle(r, s, rdf, gpu_runtime, oracle):
+    """A 3-layer stack (layer 1 filtered on a class of layer 0, layer 2 on a class of layer 1) with a conditions
+    table that chains through all three: one-call path and step-by-step path against the oracle's chain."""
+    synth = rdf.synth
+    h, w = 96, 150
+    forests = [synth.forest(3, 7, 3, "trained", 100), synth.forest(2, 8, 4, "trained", 110), synth.forest(4, 6, 3, "trained", 120)]
+    # layer0: 1 -> pixel 1, 2 -> go on (offset 3), 3 -> pixel 2; layer1 (offset 3): 1 -> 3, 2 -> 4, 3 -> go on (offset 7),
+    # 4 -> 5; layer2 (offset 7): 1 -> 6, 2 -> 7, 3 -> 8
+    conditions = [[0, 1], [1, 3], [0, 2], [0, 3], [0, 4], [1, 7], [0, 5], [0, 6], [0, 7], [0, 8]]
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(forests[0])},
+                      {"model": rdf.DecisionForest.from_numpy(forests[1]), "filter_model": 0, "filter_model_class": 2},
+                      {"model": rdf.DecisionForest.from_numpy(forests[2]), "filter_model": 1, "filter_model_class": 3}],
+           "conditions": conditions, "label_colors": [[i, i, i, 255] for i in range(8)]}
+    lf = rdf.LayeredDecisionForest(cfg, (h, w), r)
+    assert lf.num_layered_classes == 8
+    depth = synth.frames(["dense"], 555, h, w)
+    depth[0, :10, :] = 0
+    depth[0, 40:50, 60:90] = 65535
+    shape = (1, h // r, w // r)
+    l0, l1, l2, comp = (np.full(shape, 65535, np.uint16) for _ in range(4))
+    oracle.eval_forest(depth, forests[0], l0, r, None, None, s)
+    oracle.eval_forest(depth, forests[1], l1, r, l0, 2, s)
+    oracle.eval_forest(depth, forests[2], l2, r, l1, 3, s)
+    oracle.composite([l0[0], l1[0], l2[0]], np.array(conditions, np.int32), comp)
+    assert len(np.unique(comp)) >= 5, "the example should exercise several branches of the table"
+    dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
+    dbuf.cu().set(depth[0])
+    for fused in (True, False):
+        lf.fused = fused
+        lbuf.cu().fill(4242)
+        lf.run(dbuf, lbuf, s)
+        for got, want in zip(lf.label_images, (l0, l1, l2)):
+            assert np.array_equal(got.cu().get(), want[0]), f"fused={fused}"
+        assert np.array_equal(lbuf.cu().get(), comp[0]), f"fused={fused}"
+    assert lf.eval.composite_bad_pixels() == 0
