@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -68,3 +70,36 @@ def test_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "librdf_oracle" not in src, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/rdf_hip.h is what a C (or cgo / JNI / N-API) binding would include: it must compile as pedantic C99."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "rdf_hip.h"\nint main(void) { return rdf_abi_version() > 0 ? 0 : 1; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_of_the_shared_library(rdf, gpu_runtime, tmp_path):
+    """examples/eval_forest.c, built with gcc against librdf_hip.so and the HIP runtime's C API, evaluates a one-node
+    forest and checks the labels itself."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(rdf.library_path())
+    exe = tmp_path / "eval_forest_example"
+    subprocess.check_call([gcc, "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(root, "examples", "eval_forest.c"),
+                           "-L", libdir, "-l:librdf_hip.so", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "PASS" in out.stdout, (out.returncode, out.stdout, out.stderr)
