@@ -109,6 +109,8 @@ struct EvalArgs {
     uint32_t lds_tile_off; // byte offsets inside the dynamic LDS allocation
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
+    const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
+    int cpad;                  // classes rounded up to a multiple of 4
     int filter_class;
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
     int fill_untouched;    // fused pre-fill: write 65535 to every label pixel that is not evaluated
@@ -512,12 +514,29 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             const uint32_t leaf = (h[k] & ~kDone) - 2u;   // (node - 1) * 2 + side
                             any_leaf = true;
                             if (STATS && c0 == 0) st_lf++;
-                            const float *pp = a.forest +
-                                ((size_t)(kb + k) * (size_t)a.nodes + (leaf >> 1)) * (size_t)a.E +
-                                7 + (leaf & 1u) * a.C + c0;
+                            if (PACKED) {
+                                // one aligned 16-byte load per four classes from the packed PDF table (zero-padded to
+                                // cpad), instead of C scalar loads at odd offsets inside the 7+2C-float record: the
+                                // scattered leaf reads were a sixth of all L1 accesses
+                                const float4 *pp = reinterpret_cast<const float4 *>(a.packed_pdf) +
+                                    (((((size_t)(kb + k)) << a.D) + (leaf >> 1) + 1u) * 2u + (leaf & 1u)) * (size_t)(a.cpad >> 2) +
+                                    (size_t)(c0 >> 2);
 #pragma unroll
-                            for (int c = 0; c < CMAX; ++c) {
-                                if (c0 + c < a.C) pdf[c] = pdf[c] + pp[c];
+                                for (int c = 0; c < CMAX; c += 4) {
+                                    if (c0 + c < a.cpad) {
+                                        const float4 v = pp[c >> 2];
+                                        pdf[c] = pdf[c] + v.x; pdf[c + 1] = pdf[c + 1] + v.y;
+                                        pdf[c + 2] = pdf[c + 2] + v.z; pdf[c + 3] = pdf[c + 3] + v.w;
+                                    }
+                                }
+                            } else {
+                                const float *pp = a.forest +
+                                    ((size_t)(kb + k) * (size_t)a.nodes + (leaf >> 1)) * (size_t)a.E +
+                                    7 + (leaf & 1u) * a.C + c0;
+#pragma unroll
+                                for (int c = 0; c < CMAX; ++c) {
+                                    if (c0 + c < a.C) pdf[c] = pdf[c] + pp[c];
+                                }
                             }
                         }
                     }
@@ -568,6 +587,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 
 // ---- load-time repack: one thread per node; writes the 16-byte and the 32-byte table ----
 __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, NodeRec32 *packed32,
+                                              float *packed_pdf, int C, int cpad,
                                               size_t total_slots, int D, int E, float s, int force_exact)
 {
     // slot = tree * 2^D + h, h = 1-based heap index (slot h == 0 of each tree is unused and zeroed)
@@ -579,6 +599,7 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
         NodeRec32 z32 = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
         packed16[slot] = z16;
         packed32[slot] = z32;
+        for (int c = 0; c < 2 * cpad; ++c) packed_pdf[slot * 2 * (size_t)cpad + c] = 0.f;
         return;
     }
     const size_t i = tree * ((((size_t)1) << D) - 1) + (h - 1);
@@ -592,6 +613,11 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     n.pad0 = n.pad1 = 0;
     packed16[slot] = h16;
     packed32[slot] = n;
+    float *q = packed_pdf + slot * 2 * (size_t)cpad;   // [left: cpad][right: cpad], the PDFs as stored (row N of SURVEY 8a)
+    for (int c = 0; c < cpad; ++c) {
+        q[c] = c < C ? p[7 + c] : 0.f;
+        q[cpad + c] = c < C ? p[7 + C + c] : 0.f;
+    }
 }
 
 // ---- composite (tree_eval.cu:214-248): one lane per label pixel ----
@@ -902,6 +928,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         const size_t slots = (size_t)n_trees << max_depth;   // 1-based heap slots, 2^D per tree
         a.packed16 = reinterpret_cast<const NodeRec16 *>(packed);
         a.packed32 = reinterpret_cast<const NodeRec32 *>(a.packed16 + slots);
+        a.packed_pdf = reinterpret_cast<const float *>(a.packed32 + slots);
+        a.cpad = (n_classes + 3) & ~3;
     }
 
     int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
@@ -998,10 +1026,13 @@ int rdf_eval_tree(const uint16_t *depth, int n_img, int dim_x, int dim_y, const 
                        labels_out, 1, 1.0f, 1, nullptr, stream);
 }
 
-size_t rdf_forest_packed_bytes(int n_trees, int max_depth)
+static int classes_padded(int n_classes) { return (n_classes + 3) & ~3; }
+
+size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes)
 {
-    if (n_trees < 0 || max_depth < 0 || max_depth > 30) return 0;
-    return ((size_t)n_trees << max_depth) * (sizeof(NodeRec16) + sizeof(NodeRec32));
+    if (n_trees < 0 || max_depth < 0 || max_depth > 30 || n_classes < 0) return 0;
+    return ((size_t)n_trees << max_depth) *
+           (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float));
 }
 
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes, float scale_factor,
@@ -1016,7 +1047,9 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
     if (blocks >= (1ull << 31)) return RDF_ERR_TOO_LARGE;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        forest, reinterpret_cast<NodeRec16 *>(packed),
-                       reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total), total,
+                       reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total),
+                       reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32))),
+                       n_classes, classes_padded(n_classes), total,
                        max_depth, 7 + 2 * n_classes, scale_factor, g_force_exact);
     return (int)hipGetLastError();
 }

@@ -90,7 +90,7 @@ class DecisionForest:
             return hit[1]
         rt = get_runtime()
         lib = rt.lib
-        nbytes = int(lib.rdf_forest_packed_bytes(int(self.num_trees), int(self.max_depth)))
+        nbytes = int(lib.rdf_forest_packed_bytes(int(self.num_trees), int(self.max_depth), int(self.num_classes)))
         if nbytes == 0:
             return None
         buf = hit[1] if (hit is not None and hit[1].nbytes == nbytes) else DeviceArray((nbytes,), np.uint8)

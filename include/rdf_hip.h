@@ -94,12 +94,13 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers,
  * Load-time repack of a forest into a table of 16-byte hot records {23-bit floor(s*u), 23-bit
  * floor(s*v), integer threshold, leaf flags} followed by a table of 32-byte exact records
  * (fp32 s*u, s*v) that is read only for nodes whose numerators the integer form cannot
- * represent.  The reference has no counterpart: its "load" is the plain upload at
+ * represent, followed by the leaf PDFs as 16-byte aligned rows [left: C padded to a multiple of 4]
+ * [right: ...] per node.  The reference has no counterpart: its "load" is the plain upload at
  * src/decision_tree.py:148-158.  The packed tables depend on scale_factor and must be rebuilt
  * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes
- * (48 per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
+ * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
  */
-size_t rdf_forest_packed_bytes(int n_trees, int max_depth);
+size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
                     float scale_factor, void *packed, void *stream);
 

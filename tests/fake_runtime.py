@@ -35,8 +35,8 @@ class _OracleLib:
         rc = self._o.rdf_oracle_eval_tree(depth, n_img, dim_x, dim_y, tree, D, C, out, 0)
         return 0 if rc == 0 else -1
 
-    def rdf_forest_packed_bytes(self, T, D):
-        return (T << D) * 48
+    def rdf_forest_packed_bytes(self, T, D, C):
+        return (T << D) * (48 + 8 * ((C + 3) & ~3))
 
     def rdf_forest_pack(self, forest, T, D, C, s, packed, stream):
         self.calls.append(("rdf_forest_pack", T, D, C, float(s)))

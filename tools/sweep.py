@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--unpacked", action="store_true")
     ap.add_argument("--kinds", default="mixed", choices=["mixed", "interleaved", "dense", "live"])
     ap.add_argument("--reduce", type=int, default=1)
+    ap.add_argument("--classes", type=int, default=4)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=848)
     ap.add_argument("combos", nargs="*", default=["1024:81920", "512:81920", "512:32768", "256:32768", "256:16384"])
@@ -32,7 +33,7 @@ def main():
     rdf = importlib.import_module("3d-beats_amd")
     rt = rdf.get_runtime()
     lib = rt.lib
-    forest = rdf.DecisionForest.from_numpy(rdf.synth.forest(a.trees, a.depth, 4, a.topology))
+    forest = rdf.DecisionForest.from_numpy(rdf.synth.forest(a.trees, a.depth, a.classes, a.topology))
     kinds = {"mixed": None, "interleaved": ["dense", "live"] * (a.frames // 2) + ["dense"] * (a.frames % 2),
              "dense": ["dense"] * a.frames, "live": ["live"] * a.frames}[a.kinds]
     host = (rdf.synth.mixed_batch(a.frames, 0, a.height, a.width) if kinds is None
