@@ -166,6 +166,11 @@ __device__ __forceinline__ uint4 select4(bool c, const uint4 a, const uint4 b)
     return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 
+// The reference's records are 7+2C floats long, so their fields are only 4-byte aligned; gfx950 global loads do
+// not need more, and two wide loads (4 + 3 floats) replace seven scalar ones on the unpacked path.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+
 constexpr float kNumScale = 512.0f;   // a decoded numerator is 512 * (x + e), see NodeRec16
 
 struct Node {
@@ -427,9 +432,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                             for (int k = 0; k < GROUP; ++k) {
                                 const int tk = min(kb + k, a.T - 1);
                                 const float *p = a.forest + ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
-                                n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1]; n[k].bx = a.s * p[2]; n[k].by = a.s * p[3];
-                                n[k].t = thresh_to_int(p[4]);
-                                n[k].flags = child_flags(p[5], p[6]) | kFlagExact;   // fp32 numerators: IEEE divide
+                                const f4u uv = *reinterpret_cast<const f4u *>(p);
+                                const f3u tf = *reinterpret_cast<const f3u *>(p + 4);
+                                n[k].ax = a.s * uv.x; n[k].ay = a.s * uv.y; n[k].bx = a.s * uv.z; n[k].by = a.s * uv.w;
+                                n[k].t = thresh_to_int(tf.x);
+                                n[k].flags = child_flags(tf.y, tf.z) | kFlagExact;   // fp32 numerators: IEEE divide
                             }
                         }
 
@@ -534,8 +541,16 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                                     ((size_t)(kb + k) * (size_t)a.nodes + (leaf >> 1)) * (size_t)a.E +
                                     7 + (leaf & 1u) * a.C + c0;
 #pragma unroll
-                                for (int c = 0; c < CMAX; ++c) {
-                                    if (c0 + c < a.C) pdf[c] = pdf[c] + pp[c];
+                                for (int c = 0; c < CMAX; c += 4) {
+                                    if (c0 + c + 3 < a.C) {           // four classes with one (4-byte aligned) wide load
+                                        const f4u v = *reinterpret_cast<const f4u *>(pp + c);
+                                        pdf[c] = pdf[c] + v.x; pdf[c + 1] = pdf[c + 1] + v.y;
+                                        pdf[c + 2] = pdf[c + 2] + v.z; pdf[c + 3] = pdf[c + 3] + v.w;
+                                    } else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            if (c0 + c + e < a.C) pdf[c + e] = pdf[c + e] + pp[c + e];
+                                    }
                                 }
                             }
                         }
