@@ -66,6 +66,7 @@ SIGNATURES = {
     "rdf_set_lds_budget_bytes": (None, [_c_int]),
     "rdf_set_block_threads": (None, [_c_int]),
     "rdf_set_scheduler": (None, [_c_int]),
+    "rdf_set_compaction": (None, [_c_int]),
     "rdf_set_halo": (None, [_c_int]),
     "rdf_set_rows_per_wave": (None, [_c_int]),
     "rdf_set_force_exact": (None, [_c_int]),

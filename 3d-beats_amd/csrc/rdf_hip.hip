@@ -747,6 +747,7 @@ int device_info(DeviceInfo *out)
 std::mutex g_sched_mu;
 std::map<std::pair<int, void *>, int> g_sched_slot;
 std::map<int, unsigned int *> g_sched_base;     // device -> address of g_sched on that device
+int g_compaction = -1;                          // -1: filtered launches compact their pixels; 0: never
 int g_sched_mode = -1;                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic, 2 one tile per workgroup
 
 int sched_mode()
@@ -815,7 +816,7 @@ int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st);
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
 int launch_group(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    if (BLOCK == 256 && !STATS && a.filter_class != -1)   // == compact_launch in eval_common, which sized the LDS for it
+    if (BLOCK == 256 && !STATS && a.filter_class != -1 && g_compaction != 0)   // == compact_launch in eval_common, which sized the LDS for it
         return launch_compact<256, PACKED, CMAX, false, FULLROWS, GROUP, true>(a, lds_bytes, cus, st);
     return launch_compact<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP, false>(a, lds_bytes, cus, st);
 }
@@ -969,7 +970,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     const long long budget = lds_budget();
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>): two pixels
     // less halo keep five workgroups per CU
-    const bool compact_launch = block == 256 && !stats && filter_class != -1;
+    const bool compact_launch = block == 256 && !stats && filter_class != -1 && g_compaction != 0;
     int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", compact_launch ? kDefaultHalo - 2 : kDefaultHalo);
     long long tile_bytes = 0;
     // The staged tile may take half the budget.  With labels_reduce > 1 a tile spans r times the pixels per label, so
@@ -1165,6 +1166,7 @@ int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, 
 void rdf_set_lds_budget_bytes(int bytes) { g_lds_budget = bytes; }
 void rdf_set_block_threads(int threads) { g_block_threads = threads; }
 void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
+void rdf_set_compaction(int mode) { g_compaction = mode; }
 void rdf_set_halo(int pixels) { g_halo = pixels; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }

@@ -245,6 +245,7 @@ int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, 
 /* Tuning knobs (process-wide; 0 restores the default).  Not part of the reference surface. */
 void rdf_set_lds_budget_bytes(int bytes);
 void rdf_set_block_threads(int threads); /* 256, 512 or 1024 */
+void rdf_set_compaction(int mode);       /* -1 (default): filtered launches list their pixels first; 0: never */
 void rdf_set_scheduler(int mode);        /* 1 dynamic tile queue (default), 0 static round-robin, 2 one tile per
                                            workgroup (non-persistent), -1 env RDF_SCHED = static | tile */
 void rdf_set_rows_per_wave(int rows);    /* label rows per wave in a tile: 1, 2 or 4; 0 = choose by launch size */

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--kinds", default="mixed", choices=["mixed", "interleaved", "dense", "live"])
     ap.add_argument("--reduce", type=int, default=1)
     ap.add_argument("--classes", type=int, default=4)
+    ap.add_argument("--filter", type=int, default=0, help="filter on a synthetic earlier layer whose class 1 covers 1/N of "
+                    "the frame in 32x32 blocks (0: no filter)")
+    ap.add_argument("--no-compaction", action="store_true")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=848)
     ap.add_argument("combos", nargs="*", default=["1024:81920", "512:81920", "512:32768", "256:32768", "256:16384"])
@@ -42,6 +45,12 @@ def main():
     red = a.reduce
     labels = rdf.DeviceArray((host.shape[0], host.shape[1] // red, host.shape[2] // red), np.uint16).fill(65535)
     ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
+    filt = None
+    if a.filter:
+        yy, xx = np.mgrid[0:host.shape[1] // red, 0:host.shape[2] // red]
+        f2d = (((xx // 32 + yy // 32) % a.filter) == 0).astype(np.uint16)
+        filt = rdf.to_device(np.broadcast_to(f2d, (host.shape[0],) + f2d.shape).copy())
+    lib.rdf_set_compaction(0 if a.no_compaction else -1)
     combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]   # block:lds[:rows_per_wave[:halo]]
     res = {c: [] for c in combos}
     ref = None
@@ -54,7 +63,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(a.reps):
-                ev.get_labels_forest(forest, depth, labels, red)
+                ev.get_labels_forest(forest, depth, labels, red, filt, 1 if filt is not None else None)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.reps
             if r:
