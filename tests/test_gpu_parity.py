@@ -303,7 +303,7 @@ def test_bad_arguments_are_rejected(rdf, gpu_runtime):
 
 
 def test_config5_shape_bit_exact(rdf, evs, oracle):
-    """BASELINE config 5's shape: 1280x720 frames, 8-tree depth-22 forest (1.875 GiB; packed tables 3 GiB).
+    """BASELINE config 5's shape: 1280x720 frames, 8-tree depth-22 forest (1.875 GiB; packed tables 2.5 GiB).
     Two frames so that the oracle finishes in seconds."""
     synth = rdf.synth
     forest = synth.forest(8, 22, 4, "full")
