@@ -15,7 +15,7 @@
 #include <stdlib.h>
 
 template <int WIDTH, int MODE>   // WIDTH 2 or 16 bytes; MODE 0 plain, 1 sc1, 2 sc0 sc1, 3 nt
-__global__ __launch_bounds__(256) void k_loads(const char *buf, uint32_t window, int nact, int iters, uint32_t *out, uint32_t distinct = 64)
+__global__ __launch_bounds__(256) void k_loads(const char *buf, uint32_t window, int nact, int iters, uint32_t *out, uint32_t distinct = 64, int runs = 0)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_id = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_loads(const char *buf, uint32_t window,
     uint32_t off[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        uint32_t h = (wave_id * 64u + (lane % distinct)) * 2654435761u + (uint32_t)k * 40503u;   // `distinct` lines per instruction
+        uint32_t h = (wave_id * 64u + (runs ? lane / (64u / distinct) : lane % distinct)) * 2654435761u + (uint32_t)k * 40503u;   // `distinct` lines per instruction
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
         off[k] = (h % (window / 128u)) * 128u + (lane & 7u) * 16u;
     }
@@ -84,17 +84,19 @@ int main()
                 }
             }
     // lanes sharing lines: 16-byte loads, all 64 lanes active, L1-resident window, `distinct` different lines per instruction
-    printf("distinct_lines_per_instr  cycles_per_wave_instr_per_CU (16-byte loads, 64 lanes, 16 KB window)\n");
+    printf("distinct_lines_per_instr  cycles_per_wave_instr_per_CU (16-byte loads, 64 lanes, 16 KB window); first interleaved\n"
+           "(lane %% n), then in runs of consecutive lanes (lane / (64/n))\n");
+    for (int runs = 0; runs < 2; ++runs)
     for (uint32_t distinct : {1u, 4u, 16u, 64u}) {
         float ms = 0;
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL((k_loads<16, 0>), dim3(grid), dim3(256), 0, 0, buf, windows[0], 64, iters, out, distinct);
+            hipLaunchKernelGGL((k_loads<16, 0>), dim3(grid), dim3(256), 0, 0, buf, windows[0], 64, iters, out, distinct, runs);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
         }
-        printf("%8u  %8.1f\n", distinct, ms * 1e-3 * 2.4e9 / (5.0 * 4.0 * iters * 8.0));
+        printf("%s %8u  %8.1f\n", runs ? "runs       " : "interleaved", distinct, ms * 1e-3 * 2.4e9 / (5.0 * 4.0 * iters * 8.0));
     }
     return 0;
 }
