@@ -54,6 +54,7 @@ SIGNATURES = {
     "rdf_fill_u16": (_c_int, [_c_void_p, _c_size_t, ctypes.c_uint16, _c_void_p]),
     "rdf_stream_create_with_reserved_cus": (_c_int, [_c_void_p, _c_int]),
     "rdf_stream_destroy": (_c_int, [_c_void_p]),
+    "rdf_debug_sched_slots": (_c_int, [_c_void_p, _c_void_p]),
     "rdf_device_malloc": (_c_int, [_c_void_p, _c_size_t]),
     "rdf_device_free": (_c_int, [_c_void_p]),
     "rdf_ipc_export": (_c_int, [_c_void_p, _c_void_p]),
@@ -68,6 +69,9 @@ SIGNATURES = {
     "rdf_set_scheduler": (None, [_c_int]),
     "rdf_set_compaction": (None, [_c_int]),
     "rdf_set_halo": (None, [_c_int]),
+    "rdf_set_lds_levels": (None, [_c_int]),
+    "rdf_set_stage_vec": (None, [_c_int]),
+    "rdf_set_blocked": (None, [_c_int]),
     "rdf_set_rows_per_wave": (None, [_c_int]),
     "rdf_set_force_exact": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),

@@ -50,12 +50,15 @@ constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer
 constexpr int kDefaultLdsBudget = 32700;   // node table + depth tile per workgroup
 constexpr int kDefaultHalo = 24;   // depth pixels staged around a tile's centres
 constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
-constexpr int kSchedSlots = 256;
+constexpr int kSchedSlots = 256;        // one per (device, stream) that launches directly
+constexpr int kGraphSlots = 768;        // one per launch recorded into a hipGraph (stream capture)
 
-// Dynamic tile queue state, one slot per (device, stream) in use: {next tile, workgroups finished}.
-// Zero at rest: the last workgroup of a launch resets its slot, so launches need no memset and
-// replay correctly from a captured hipGraph.
-__device__ unsigned int g_sched[kSchedSlots][2];
+// Dynamic tile queue state: {next tile, workgroups finished}.  One slot per (device, stream) that launches directly
+// (launches on one stream run in order, so they never meet in a slot) and a slot of its own for every launch recorded
+// into a hipGraph: a graph replays on whatever stream it is launched on, so its launch must not share the slot of the
+// stream it happened to be captured on (an executable graph never runs concurrently with itself).
+// Zero at rest: the last workgroup of a launch resets its slot, so launches need no memset and replay correctly.
+__device__ unsigned int g_sched[kSchedSlots + kGraphSlots][2];
 
 // ---- node records --------------------------------------------------------------------------
 // Hot record, 16 bytes, one 128-bit load per node.  Each word carries a numerator in its high 23 bits, a zero
@@ -74,6 +77,36 @@ __device__ unsigned int g_sched[kSchedSlots][2];
 // tools/verify_payload.hip (1.2e14, 2.1e14 and 1.4e14 cases, 0 mismatches; logs under profiles/).  Any other
 // numerator (huge, denormal, inf, NaN) flags the node kFlagExact and the kernel takes the IEEE divide on the
 // fp32 values of the exact record.
+// ---- deep levels: subtree-blocked copy of the hot records --------------------------------------
+// The heap order of the reference (cu_utils.hpp:32-39) puts a node's children 2^j records away: below the levels that
+// stay resident in L2 every level of a lane's walk is another 128-byte line from the Infinity Cache or HBM.  The packed
+// table therefore holds the hot records of levels >= k0 a second time, grouped into 3-level subtrees: the root at
+// level k0 + 3b, its two children and four grandchildren are records 0, 1-2, 3-6 of ONE aligned 128-byte line (the
+// eighth slot is unused), so three levels of a walk cost one line from beyond L2 instead of three.  k0 is 4, 5 or 6,
+// whichever makes (D - k0) a multiple of 3, so that the last block is full; block level b of a tree starts at byte
+// 128 * 2^k0 * (8^b - 1) / 7.  Forests with D < 7 have no blocked table (k0 = D).
+__host__ __device__ inline int blocked_k0(int D) { return D >= 7 ? 4 + (D - 4) % 3 : D; }
+__host__ __device__ inline size_t blocked_level_offset(int k0, int b)
+{
+    size_t n = 0, w = (size_t)1 << k0;
+    for (int i = 0; i < b; ++i, w <<= 3) n += w;
+    return n * 128u;
+}
+__host__ __device__ inline size_t blocked_tree_bytes(int D)
+{
+    const int k0 = blocked_k0(D);
+    return blocked_level_offset(k0, (D - k0) / 3);
+}
+// byte offset of heap node h (1-based, level j >= k0) inside its tree's blocked table
+__host__ __device__ inline size_t blocked_node_offset(int k0, int j, size_t h)
+{
+    const int b = (j - k0) / 3, t = (j - k0) - 3 * b;
+    const size_t root = h >> t;                                   // ancestor on the block's root level j - t
+    const size_t r = root - ((size_t)1 << (j - t));               // its index on that level
+    const size_t p = (((size_t)1 << t) - 1) + (h & (((size_t)1 << t) - 1));
+    return blocked_level_offset(k0, b) + r * 128u + p * 16u;
+}
+
 struct alignas(16) NodeRec16 {
     uint32_t w[4];
 };
@@ -106,10 +139,16 @@ struct EvalArgs {
     int lds_levels;        // top levels held in LDS
     int halo;              // depth pixels around the tile's centres held in LDS
     int tw, th, twp;       // staged depth tile: width, height, row pitch (0: no staged tile)
+    uint32_t stage_tw8;    // > 0: stage with 16-byte loads, tw / 8 vectors per row (W, tx0 and twp are multiples of 8)
+    uint32_t stage_magic;  // floor(2^32 / stage_tw8) + 1: i / stage_tw8 == umulhi(i, magic) for i < 2^32 / stage_tw8
     uint32_t lds_tile_off; // byte offsets inside the dynamic LDS allocation
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
+    const char *blocked;       // hot records of levels >= blk_k0 again, as 3-level subtrees of 7 records in one 128-byte line
+    uint32_t blk_tree_bytes;   // bytes of one tree's blocked table
+    int blk_k0;                // first blocked level (>= D: no blocked table); (D - blk_k0) % 3 == 0
+    uint32_t blk_off[9];       // byte offset of block level b = levels blk_k0 + 3b .. + 2 inside a tree's table
     int cpad;                  // classes rounded up to a multiple of 4
     int filter_class;
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
@@ -285,7 +324,22 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         }
 
         // ---- stage depth [ty0, ty0+th) x [tx0, tx0+tw) into LDS; outside the image = 65535 ----
-        if (tw > 0) {
+        if (a.stage_tw8 > 0u) {
+            // eight pixels per lane (one 128-bit load, one ds_write_b128): W, tx0 and the row pitch are multiples of 8, so
+            // a vector lies inside or outside the image as a whole and every address is 16-byte aligned
+            const uint32_t total = (uint32_t)th * a.stage_tw8;
+            for (uint32_t i = (uint32_t)tid; i < total; i += BLOCK) {
+                const uint32_t row = __umulhi(i, a.stage_magic);
+                const uint32_t c = (i - row * a.stage_tw8) << 3;
+                const int gy = ty0 + (int)row, gx = tx0 + (int)c;
+                uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                if ((uint32_t)gy < (uint32_t)a.H && (uint32_t)gx < (uint32_t)a.W)
+                    v = *reinterpret_cast<const uint4 *>(
+                        depth_b + (img_boff + ((__umul24((uint32_t)gy, (uint32_t)a.W) + (uint32_t)gx) << 1)));
+                *reinterpret_cast<uint4 *>(lds_tile + row * (uint32_t)twp + c) = v;
+            }
+            __syncthreads();
+        } else if (tw > 0) {
             for (int row = (int)wave; row < th; row += (int)kWaves) {
                 const int gy = ty0 + row;
                 const bool row_in = (uint32_t)gy < (uint32_t)a.H;
@@ -411,14 +465,30 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 
                         const bool in_lds = j < K;
                         Node n[GROUP];
-                        uint32_t hn[GROUP];   // node to fetch: a finished or idle slot re-reads the root (cheap, discarded)
+                        uint32_t hn[GROUP];   // node to fetch: a finished or idle slot reads the level's first node (discarded)
 #pragma unroll
-                        for (int k = 0; k < GROUP; ++k) hn[k] = (int)h[k] > 0 ? h[k] : 1u;
+                        for (int k = 0; k < GROUP; ++k) hn[k] = (int)h[k] > 0 ? h[k] : (1u << j);   // (the level's first node: valid in every table)
                         if (in_lds) {
 #pragma unroll
                             for (int k = 0; k < GROUP; ++k) {
                                 const uint32_t tk = (uint32_t)min(kb + k, a.T - 1);   // wave-uniform
                                 n[k] = decode_node(lds_nodes[tk * lds_pitch + hn[k]]);
+                            }
+                        } else if (PACKED && j >= a.blk_k0) {
+                            // subtree-blocked table: (root of the 3-level block) * 128 + (place inside the block) * 16.
+                            // j is wave-uniform, so the block level, the depth t inside the block and every constant
+                            // below live in scalar registers; the 2^(j-t) that turns the root's heap index into its
+                            // index on its level is folded into the scalar base (mod 2^32: offsets stay below 2^32).
+                            const int jj = j - a.blk_k0;
+                            const int bl = jj / 3, t = jj - 3 * bl;
+                            const uint32_t mask = (1u << t) - 1u;
+                            const uint32_t sbase = a.blk_off[bl] - ((1u << (j - t)) << 7) + (mask << 4);
+#pragma unroll
+                            for (int k = 0; k < GROUP; ++k) {
+                                const int tk = min(kb + k, a.T - 1);
+                                const char *base = a.blocked + (size_t)tk * a.blk_tree_bytes;
+                                const uint32_t off = sbase + ((hn[k] >> t) << 7) + ((hn[k] & mask) << 4);
+                                n[k] = decode_node(*reinterpret_cast<const uint4 *>(base + off));
                             }
                         } else if (PACKED) {
 #pragma unroll
@@ -602,7 +672,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 
 // ---- load-time repack: one thread per node; writes the 16-byte and the 32-byte table ----
 __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, NodeRec32 *packed32,
-                                              float *packed_pdf, int C, int cpad,
+                                              float *packed_pdf, char *blocked, int C, int cpad,
                                               size_t total_slots, int D, int E, float s, int force_exact)
 {
     // slot = tree * 2^D + h, h = 1-based heap index (slot h == 0 of each tree is unused and zeroed)
@@ -628,6 +698,16 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     n.pad0 = n.pad1 = 0;
     packed16[slot] = h16;
     packed32[slot] = n;
+    const int k0 = blocked_k0(D), lvl = 63 - __clzll((unsigned long long)h);
+    if (lvl >= k0) {
+        char *bt = blocked + tree * blocked_tree_bytes(D);
+        const size_t off = blocked_node_offset(k0, lvl, h);
+        *reinterpret_cast<NodeRec16 *>(bt + off) = h16;
+        if ((off & 127u) == 0u) {   // the block's root also clears the unused eighth slot
+            NodeRec16 z16 = {{0u, 0u, 0u, 0u}};
+            *reinterpret_cast<NodeRec16 *>(bt + off + 112u) = z16;
+        }
+    }
     float *q = packed_pdf + slot * 2 * (size_t)cpad;   // [left: cpad][right: cpad], the PDFs as stored (row N of SURVEY 8a)
     for (int c = 0; c < cpad; ++c) {
         q[c] = c < C ? p[7 + c] : 0.f;
@@ -760,6 +840,10 @@ int sched_mode()
     return mode;
 }
 
+std::map<int, std::vector<int>> g_sched_free;   // device -> stream slots given back by rdf_stream_destroy
+std::map<int, int> g_sched_next;                // device -> stream slots handed out so far
+std::map<int, int> g_graph_next;                // device -> graph slots handed out so far
+
 unsigned int *sched_slot(void *stream)
 {
     if (sched_mode() != 1) return nullptr;
@@ -772,13 +856,26 @@ unsigned int *sched_slot(void *stream)
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched)) != hipSuccess || !p) return nullptr;
         bit = g_sched_base.emplace(dev, reinterpret_cast<unsigned int *>(p)).first;
     }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) == hipSuccess &&
+        cap == hipStreamCaptureStatusActive) {
+        int &n = g_graph_next[dev];
+        if (n >= kGraphSlots) return nullptr;   // static tiles: slower on uneven batches, never wrong
+        return bit->second + 2 * (kSchedSlots + n++);
+    }
     const auto key = std::make_pair(dev, stream);
     auto it = g_sched_slot.find(key);
     if (it == g_sched_slot.end()) {
-        int used = 0;
-        for (const auto &kv : g_sched_slot) used += kv.first.first == dev;
-        if (used >= kSchedSlots) return nullptr;
-        it = g_sched_slot.emplace(key, used).first;
+        int slot = -1;
+        auto &fl = g_sched_free[dev];
+        if (!fl.empty()) {
+            slot = fl.back();
+            fl.pop_back();
+        } else if (g_sched_next[dev] < kSchedSlots) {
+            slot = g_sched_next[dev]++;
+        }
+        if (slot < 0) return nullptr;
+        it = g_sched_slot.emplace(key, slot).first;
     }
     return bit->second + 2 * it->second;
 }
@@ -910,6 +1007,9 @@ int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void 
 }
 
 int g_halo = -1;
+int g_lds_levels = -1;
+int g_blocked = -1;
+int g_stage_vec = -1;
 int g_rows_per_wave = 0;
 int g_force_exact = 0;
 
@@ -946,6 +1046,13 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         a.packed32 = reinterpret_cast<const NodeRec32 *>(a.packed16 + slots);
         a.packed_pdf = reinterpret_cast<const float *>(a.packed32 + slots);
         a.cpad = (n_classes + 3) & ~3;
+        a.blocked = reinterpret_cast<const char *>(a.packed_pdf + slots * 2 * (size_t)a.cpad);
+        a.blk_tree_bytes = (uint32_t)blocked_tree_bytes(max_depth);
+        const int use_blocked = g_blocked >= 0 ? g_blocked : env_int("RDF_BLOCKED", 1);
+        a.blk_k0 = use_blocked ? blocked_k0(max_depth) : max_depth;
+        for (int b = 0; b < 9; ++b) a.blk_off[b] = (uint32_t)blocked_level_offset(blocked_k0(max_depth), b < 8 ? b : 8);
+    } else {
+        a.blk_k0 = max_depth;
     }
 
     int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
@@ -979,21 +1086,39 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // centres fit is the tile dropped.
     // (Throughput shape only: for a single small frame staging a narrow tile cost more than it saved, 91 vs 87 us.)
     const int h_min = rpw == kMaxRowsPerWave ? 0 : halo;
+    // pixel list: one uint16 per tile pixel, then one uint32 per tile row
+    const long long list_bytes = compact_launch ? (((long long)block * rpw * 2 + (long long)tile_rows * 4) + 15) & ~15ll : 0;
+    // levels of the forest the caller pinned into LDS (rdf_set_lds_levels): the tile then gets all that is left of the
+    // budget instead of half of it
+    int k_forced = g_lds_levels >= 0 ? g_lds_levels : env_int("RDF_LDS_LEVELS", -1);
+    if (k_forced > max_depth) k_forced = max_depth;
+    while (k_forced > 0 && (long long)n_trees * (1ll << k_forced) * 16 + 32 + list_bytes > budget) --k_forced;
+    const long long tile_budget = k_forced >= 0 ? budget - 32 - list_bytes - (k_forced > 0 ? (long long)n_trees * (1ll << k_forced) * 16 : 0)
+                                                : budget / 2;
+    // 16-byte staging needs every row start 16-byte aligned in the image and in LDS
+    const int want_vec = g_stage_vec >= 0 ? g_stage_vec : env_int("RDF_STAGE_VEC", 1);
+    const bool vec_ok = want_vec && dim_x % 8 == 0 && ((64 * r) % 8 == 0) && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0;
     for (int h = halo; h >= h_min && h >= 0; h -= 2) {
-        const long long tw = 63ll * r + 1 + 2ll * h;
+        const bool vec = vec_ok && h % 8 == 0;
+        long long tw = 63ll * r + 1 + 2ll * h;
         const long long th = ((long long)tile_rows - 1) * r + 1 + 2ll * h;
-        const long long twp = (tw + 1) & ~1ll;
+        if (vec) tw = (tw + 7) & ~7ll;                      // a few more columns than the probes' reach: harmless
+        long long twp = vec ? tw : (tw + 1) & ~1ll;
+        if (vec && (twp * 2) % 512 == 0) twp += 8;          // not a whole number of LDS bank sweeps per row
         const long long bytes = (th * twp * 2 + 15) & ~15ll;
-        if (bytes <= budget / 2) {
+        if (bytes <= tile_budget) {
             tile_bytes = bytes;
             a.halo = h; a.tw = (int)tw; a.th = (int)th; a.twp = (int)twp;
+            if (vec) {
+                a.stage_tw8 = (uint32_t)(tw >> 3);
+                a.stage_magic = (uint32_t)((1ull << 32) / a.stage_tw8) + 1u;
+            }
             break;
         }
     }
-    // pixel list: one uint16 per tile pixel, then one uint32 per tile row
-    const long long list_bytes = compact_launch ? (((long long)block * rpw * 2 + (long long)tile_rows * 4) + 15) & ~15ll : 0;
     int K = 0;
-    while (K < max_depth && (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 32 + list_bytes <= budget) ++K;
+    while (K < max_depth && (k_forced < 0 || K < k_forced) &&
+           (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 32 + list_bytes <= budget) ++K;
     a.lds_levels = K;
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
     a.lds_tile_off = (uint32_t)(node_bytes + 16);
@@ -1010,7 +1135,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
                       : launch_block<false, true>(block, a, lds_bytes, cus, st);
     }
     return packed ? launch_block<true, false>(block, a, lds_bytes, cus, st)
-                  : launch_block<false, false>(block, a, lds_bytes, di.cus, st);
+                  : launch_block<false, false>(block, a, lds_bytes, cus, st);
 }
 
 } // namespace
@@ -1048,7 +1173,8 @@ size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes)
 {
     if (n_trees < 0 || max_depth < 0 || max_depth > 30 || n_classes < 0) return 0;
     return ((size_t)n_trees << max_depth) *
-           (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float));
+               (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float)) +
+           (size_t)n_trees * blocked_tree_bytes(max_depth);
 }
 
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes, float scale_factor,
@@ -1065,6 +1191,8 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
                        forest, reinterpret_cast<NodeRec16 *>(packed),
                        reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total),
                        reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32))),
+                       reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32) +
+                                                                   2 * (size_t)classes_padded(n_classes) * sizeof(float)),
                        n_classes, classes_padded(n_classes), total,
                        max_depth, 7 + 2 * n_classes, scale_factor, g_force_exact);
     return (int)hipGetLastError();
@@ -1114,7 +1242,9 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers, c
     if (!composite_out) return RDF_ERR_NULL_PTR;
     for (int i = 0; i < n_layers; ++i) {
         const int fl = filter_layer[i];
-        if (fl >= n_layers) return RDF_ERR_BAD_ARG;
+        // a layer may only filter on an EARLIER layer here: the fills of LayeredDecisionForest.run are folded into the
+        // kernels, so a later layer's buffer still holds the previous frame (the host wrapper takes the step-by-step path)
+        if (fl >= i) return RDF_ERR_BAD_ARG;
         const uint16_t *filt = fl >= 0 ? layer_labels[fl] : nullptr;
         const void *pk = packed ? packed[i] : nullptr;
         if (pk && max_depth[i] > 27) pk = nullptr;
@@ -1168,6 +1298,9 @@ void rdf_set_block_threads(int threads) { g_block_threads = threads; }
 void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
 void rdf_set_compaction(int mode) { g_compaction = mode; }
 void rdf_set_halo(int pixels) { g_halo = pixels; }
+void rdf_set_lds_levels(int levels) { g_lds_levels = levels; }
+void rdf_set_blocked(int on) { g_blocked = on; }
+void rdf_set_stage_vec(int on) { g_stage_vec = on; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }
 
@@ -1196,12 +1329,36 @@ int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved)
 }
 int rdf_stream_destroy(void *stream)
 {
+    // the stream's work is over once hipStreamDestroy returns: its queue slot (zero at rest) can serve another stream
+    const hipError_t e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
     {
         std::lock_guard<std::mutex> lock(g_sched_mu);
         for (auto it = g_stream_cus.begin(); it != g_stream_cus.end();)
             it = it->first.second == stream ? g_stream_cus.erase(it) : std::next(it);
+        for (auto it = g_sched_slot.begin(); it != g_sched_slot.end();) {
+            if (it->first.second == stream) {
+                g_sched_free[it->first.first].push_back(it->second);
+                it = g_sched_slot.erase(it);
+            } else {
+                ++it;
+            }
+        }
     }
-    return (int)hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+    const hipError_t d = hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+    return (int)(d != hipSuccess ? d : e);
+}
+
+// test hook: how many stream slots / graph slots the current device has handed out and how many were given back
+int rdf_debug_sched_slots(int *stream_slots_in_use, int *graph_slots_used)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    int used = 0;
+    for (const auto &kv : g_sched_slot) used += kv.first.first == dev;
+    if (stream_slots_in_use) *stream_slots_in_use = used;
+    if (graph_slots_used) *graph_slots_used = g_graph_next[dev];
+    return RDF_OK;
 }
 
 // ---- peer-to-peer plumbing for the multi-GPU gather (3d-beats_amd/distributed.py): the root

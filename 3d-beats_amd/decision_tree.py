@@ -138,6 +138,12 @@ class LayeredDecisionForest:
         self.num_models = len(self.m)
         for i, (_, fm, _) in enumerate(self.m):
             assert fm is None or 0 <= fm < self.num_models, f"layer {i}: filter_model {fm} out of range"
+            # A layer that filters on itself or on a LATER layer reads labels that this frame has not produced yet.  The
+            # reference fills every label buffer with 65535 first (decision_tree.py:237-240), so such a layer sees only
+            # 65535; the fused call folds the fills into the kernels and would read the previous frame's labels instead:
+            # such stacks take the step-by-step path, which is the reference's sequence launch for launch.
+            if fm is not None and fm >= i:
+                self.fused = False
 
         self.label_images = [GpuBuffer(self.labels_dims, dtype=np.uint16) for _ in range(self.num_models)]
 
@@ -149,6 +155,7 @@ class LayeredDecisionForest:
         # conditions rows: (0, PIXEL_ID) or (1, NEXT_IMG_CONDITION_OFFSET); see decision_tree.py:209-220
         labels_conditions = np.array(cfg['conditions'], dtype=np.int32)
         assert labels_conditions.ndim == 2 and labels_conditions.shape[1] == 2
+        self._cfg_host = {'conditions': labels_conditions.tolist(), 'label_colors': np.array(cfg['label_colors']).tolist()}
         self.labels_conditions_cu = GpuBuffer(labels_conditions.shape, dtype=np.int32)
         self.labels_conditions_cu.cu().set(labels_conditions)
         self.num_layered_classes = int(max([c[1] for c in filter(lambda c: c[0] == 0, labels_conditions)]))
@@ -157,6 +164,23 @@ class LayeredDecisionForest:
         assert label_colors.shape == (self.num_layered_classes, 4)
         self.label_colors = GpuBuffer(label_colors.shape, dtype=np.uint8)
         self.label_colors.cu().set(label_colors)
+
+    def sibling(self):
+        """A second stack over the SAME forests (device tables and packed tables are shared), conditions and colours, with
+        its own per-layer label buffers, pointer table and evaluator.  run() writes `label_images` and the evaluator's
+        error counter, so two runs that may be in flight together -- the two hands of a frame on two streams, two captured
+        graphs -- must not go through one LayeredDecisionForest object; give each its own sibling.  (The reference app
+        shares one object between the hands because it runs them one after the other on one stream, 3d_bz.py:281-284.)"""
+        layers = []
+        for m, fm, fc in self.m:
+            l = {'model': m}
+            if fm is not None:
+                l['filter_model'], l['filter_model_class'] = fm, fc
+            layers.append(l)
+        cfg = {'layers': layers, 'conditions': self._cfg_host['conditions'], 'label_colors': self._cfg_host['label_colors']}
+        other = LayeredDecisionForest(cfg, self.depth_dims, self.labels_reduce, fused=self.fused)
+        other.eval.use_packed = self.eval.use_packed
+        return other
 
     def run(self, depth_image, labels_image, scale_factor=1.):
         """Per-frame entry of the live apps (run_live_layered.py:126, 3d_bz.py:389-437): every label buffer ends

@@ -25,6 +25,13 @@ class HandPipeline:
         plane's 4x4 matrix (calibrated_plane.plane); fingertip_idxes = 1-based composite label ids (3d_bz.py:112)."""
         self._rt = get_runtime()
         self._lib = self._rt.lib
+        # run() writes the stack's per-layer label buffers: a stack that already serves another pipeline is replaced by a
+        # sibling (same forests and tables, own label buffers), so that two pipelines -- the two hands of a frame -- can be
+        # in flight together on two streams without overwriting each other's layer-0 labels.  `self.layered_rdf` is the
+        # stack this pipeline really runs.
+        if getattr(layered_rdf, "_pipeline_owner", None) is not None:
+            layered_rdf = layered_rdf.sibling()
+        layered_rdf._pipeline_owner = self
         self.layered_rdf = layered_rdf
         self.DIM_Y, self.DIM_X = int(depth_dims[0]), int(depth_dims[1])
         self.LABELS_REDUCE = int(labels_reduce)
@@ -62,7 +69,10 @@ class HandPipeline:
         function that replays it on the buffers' current contents and returns what run() returns: one graph
         launch per hand per frame instead of ~16 kernel launches.  replay(read=False) only enqueues (replay.read()
         fetches the result later), so the two hands of a frame -- two HandPipeline objects, each captured under its
-        own torch stream -- can be in flight together."""
+        own torch stream -- can be in flight together.  Each pipeline owns every buffer its graph writes, the layered
+        forest's per-layer label images included (__init__ takes a sibling of a stack that another pipeline already
+        uses); the recorded forest launches get tile-queue slots of their own (rdf_hip.hip, g_sched), so a replay may
+        run on any stream."""
         import torch
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):      # warm-up on the capture stream: workspaces, occupancy queries, queue slot

@@ -98,13 +98,17 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers,
  * [right: ...] per node.  The reference has no counterpart: its "load" is the plain upload at
  * src/decision_tree.py:148-158.  The packed tables depend on scale_factor and must be rebuilt
  * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes
- * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
+ * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree, plus the subtree-blocked copy of the
+ * hot records of the levels below the top k0 = 4..6: 128 * 2^k0 * (8^((max_depth - k0) / 3) - 1) / 7 bytes per tree, in
+ * which a node, its children and grandchildren share one 128-byte line).  Packed tables support max_depth <= 27 (32-bit
+ * byte offsets inside one tree).
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
                     float scale_factor, void *packed, void *stream);
 
-/* rdf_eval_forest on a packed table; `forest` (original layout) is still read for leaf PDFs. */
+/* rdf_eval_forest on a packed table (hot records, exact records and leaf PDFs are all read from `packed`); `forest`
+ * (original layout) is only used when `packed` is NULL for a degenerate forest (no tree or depth 0). */
 int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_y,
                            const void *packed, const float *forest,
                            int n_trees, int max_depth, int n_classes,
@@ -222,9 +226,13 @@ int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
 
 /* A stream whose kernels leave the first n_reserved CUs (hipExtStreamCreateWithCUMask numbering; use a multiple of 32 =
  * one CU per shader engine on MI355X) to other streams, for running the forest kernel next to RCCL: DESIGN.md section 6.
- * rdf_stream_destroy releases it. */
+ * rdf_stream_destroy waits for the stream's work, gives its tile-queue slot back and destroys it (call it for any stream
+ * that launched forest kernels and is going away: a device has 256 stream slots; beyond them launches fall back to
+ * static tiles). */
 int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved);
 int rdf_stream_destroy(void *stream);
+/* test hook: tile-queue slots of the current device held by streams / handed to launches recorded into hipGraphs */
+int rdf_debug_sched_slots(int *stream_slots_in_use, int *graph_slots_used);
 /* Peer-to-peer plumbing for the multi-GPU gather (no reference counterpart): a raw device allocation
  * whose 64-byte IPC handle another process of the node opens to get a pointer it can copy into.  rdf_memcpy_device_async
  * is hipMemcpyAsync(hipMemcpyDefault): device-to-device copies between GPUs run on the copy engines, not on CUs. */
@@ -249,7 +257,11 @@ void rdf_set_compaction(int mode);       /* -1 (default): filtered launches list
 void rdf_set_scheduler(int mode);        /* 1 dynamic tile queue (default), 0 static round-robin, 2 one tile per
                                            workgroup (non-persistent), -1 env RDF_SCHED = static | tile */
 void rdf_set_rows_per_wave(int rows);    /* label rows per wave in a tile: 1, 2 or 4; 0 = choose by launch size */
-void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (16) */
+void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (24) */
+void rdf_set_lds_levels(int levels);     /* top levels of every tree pinned in LDS (the depth tile then gets the rest of
+                                            the LDS budget instead of half of it); -1 = fill what the tile leaves */
+void rdf_set_blocked(int on);            /* deep levels read from the subtree-blocked copy of the packed table: 1/-1 (default) on, 0 off */
+void rdf_set_stage_vec(int on);          /* tile staging with 16-byte loads where alignment allows: 1/-1 (default) on, 0 off */
 void rdf_set_force_exact(int on);        /* test knob: rdf_forest_pack flags every node for the IEEE-divide path */
 
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */

@@ -71,8 +71,13 @@ def main():
         with torch.cuda.stream(s2):
             b = r2.read()
         return a, b
+    # each pipeline owns the label buffers its graph writes (pipe2 took a sibling of `lf`): the two hands in flight together
+    # must give what they give one after the other
+    seq = (pipe.run(dbuf, gbuf, 1, False), pipe2.run(dbuf, gbuf, 2, True))
     for _ in range(20):
-        both()
+        got = both()
+        for (gm, gh), (wm, wh) in zip(got, seq):
+            assert np.array_equal(gm.view(np.uint64), wm.view(np.uint64)) and np.array_equal(gh.view(np.uint64), wh.view(np.uint64))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):

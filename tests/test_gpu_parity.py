@@ -187,6 +187,44 @@ def test_launch_geometry_does_not_change_results(block, lds, halo, sched, rdf, g
         lib.rdf_set_scheduler(-1)
 
 
+@pytest.mark.parametrize("block,lds,halo,levels,vec", [(256, 0, 24, -1, 1), (256, 0, 24, -1, 0), (256, 0, 16, 3, 1),
+                                                      (1024, 163840, 96, 8, 1), (1024, 163840, 88, 6, 1),
+                                                      (512, 81920, 64, 8, 1), (512, 81920, 40, 0, 1),
+                                                      (1024, 163840, 200, 8, 1), (256, 20000, 8, 12, 1)])
+def test_vector_staging_and_pinned_levels_do_not_change_results(block, lds, halo, levels, vec, rdf, gpu_runtime, evs, oracle):
+    """16-byte tile staging (frame width and halo multiples of 8), also with the forest's top levels pinned in LDS and the
+    depth tile taking the rest of the budget (big halos, one workgroup per CU), equals the oracle; so does a frame whose
+    width rules the vector path out."""
+    synth = rdf.synth
+    forest = synth.forest(4, 12, 4, "trained", first_tree=11)
+    lib = gpu_runtime.lib
+    lib.rdf_set_block_threads(block)
+    lib.rdf_set_lds_budget_bytes(lds if lds else 1)
+    lib.rdf_set_halo(halo)
+    lib.rdf_set_lds_levels(levels)
+    lib.rdf_set_stage_vec(vec)
+    try:
+        for (h, w) in ((136, 200), (97, 72), (130, 203)):
+            depth = synth.frames(["live", "dense", "live"], 710, h, w)
+            depth[1, :3, :] = 65535
+            depth[1, :, -9:] = 0
+            for r, s in ((1, 1.0), (2, 0.5), (4, 2.0)):
+                filt = (np.random.default_rng(h + r).integers(0, 3, size=(3, h // r, w // r))).astype(np.uint16)
+                for use_filter in (False, True):
+                    want = np.full((3, h // r, w // r), 65535, np.uint16)
+                    oracle.eval_forest(depth, forest, want, r, filt if use_filter else None, 1 if use_filter else None, s)
+                    for path in ("packed", "direct"):
+                        got = _gpu_forest(rdf, evs[path], depth, forest, 65535, r, filt if use_filter else None,
+                                          1 if use_filter else None, s)
+                        assert np.array_equal(got, want), (block, lds, halo, levels, vec, h, w, path, r, use_filter)
+    finally:
+        lib.rdf_set_block_threads(0)
+        lib.rdf_set_lds_budget_bytes(0)
+        lib.rdf_set_halo(-1)
+        lib.rdf_set_lds_levels(-1)
+        lib.rdf_set_stage_vec(-1)
+
+
 ADVERSARIAL = [8388607.5, 8388607.0, 8388608.0, -8388608.0, -8388608.5, -8388607.5, 16777216.0, 3e9, -3e9, 1e-30,
                -1e-30, 1e-45, -1e-45, 2.0 ** -87, -(2.0 ** -87), 2.0 ** -88, 11.999999, -11.999999, 23.999998,
                0.99999994, -0.99999994, -1.0000001, 65534.0, 65533.996, 131067.99, 4000.0, 3999.9998, -4000.0,
@@ -355,6 +393,8 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
         for it in range(rounds):
             T, D, C = int(rng.integers(1, 10)), int(rng.integers(1, 12)), int(rng.integers(1, 20))
             n, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 90)), int(rng.integers(1, 200))
+            if rng.random() < 0.4:
+                w = max(8, w & ~7)      # widths the 16-byte tile staging accepts
             r = int(rng.choice([1, 1, 2, 3, 7]))
             s = float(rng.choice([1.0, 0.5, 0.25, 1.5, 2.0]))
             forest = rdf.synth.forest(T, D, C, str(rng.choice(["full", "trained"])), first_tree=it)
@@ -369,7 +409,9 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
             filt = rng.integers(0, 3, size=(n, h // r, w // r)).astype(np.uint16) if use_filter else None
             prefill = int(rng.choice([65535, 0, 31337]))
             lib.rdf_set_block_threads(int(rng.choice([0, 256, 512, 1024])))
-            lib.rdf_set_halo(int(rng.choice([-1, 0, 5, 16, 33])))
+            lib.rdf_set_halo(int(rng.choice([-1, 0, 5, 16, 33, 48])))
+            lib.rdf_set_lds_levels(int(rng.choice([-1, -1, 0, 2, 9])))
+            lib.rdf_set_stage_vec(int(rng.choice([-1, -1, 0])))
             lib.rdf_set_rows_per_wave(int(rng.choice([0, 1, 2, 4])))
             lib.rdf_set_scheduler(int(rng.choice([-1, 0, 1, 2])))
             lib.rdf_set_lds_budget_bytes(int(rng.choice([0, 1, 9000, 40000, 120000])))
@@ -381,6 +423,8 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
     finally:
         lib.rdf_set_block_threads(0)
         lib.rdf_set_halo(-1)
+        lib.rdf_set_lds_levels(-1)
+        lib.rdf_set_stage_vec(-1)
         lib.rdf_set_rows_per_wave(0)
         lib.rdf_set_scheduler(-1)
         lib.rdf_set_lds_budget_bytes(0)

@@ -167,6 +167,44 @@ def test_layered_forest_fused_run_equals_stepwise(rdf, host_runtime, tmp_path):
     assert np.array_equal(labels.cu().get(), g["g3_comp"][0])
 
 
+def test_layer_filtering_on_a_later_layer_takes_the_reference_sequence(rdf, host_runtime, tmp_path):
+    """decision_tree.py:237-257 fills every label buffer with 65535 BEFORE the first layer runs, so a layer whose
+    filter_model is itself or a later layer sees only 65535 and classifies nothing -- frame after frame.  The fused call
+    folds the fills into the kernels (a later layer's buffer would still hold the previous frame), so such stacks must take
+    the step-by-step path."""
+    g = np.load(GOLDEN)
+    cfg = json.loads(open(_write_layered_cfg(tmp_path, g)).read())
+    cfg["root"] = str(tmp_path)
+    cfg["layers"][0]["filter_model"], cfg["layers"][0]["filter_model_class"] = 1, 2    # layer 0 filtered on layer 1
+    lf = rdf.LayeredDecisionForest(cfg, (60, 84), 2)
+    assert not lf.fused
+    depth, labels = rdf.GpuBuffer((60, 84), np.uint16), rdf.GpuBuffer((30, 42), np.uint16)
+    depth.cu().set(g["g3_depth"][0])
+    for _ in range(2):          # the second frame must not see the first frame's layer-1 labels
+        lf.run(depth, labels, 1.0)
+        assert (lf.label_images[0].cu().get() == 65535).all()
+        assert (lf.label_images[1].cu().get() == 65535).all()     # filtered on class 3 of an all-65535 layer 0
+        assert (labels.cu().get() == 65535).all()
+    assert not any(c[0] == "rdf_layered_run" for c in host_runtime.lib.calls)
+
+
+def test_sibling_stack_shares_forests_but_not_label_buffers(rdf, host_runtime, tmp_path):
+    g = np.load(GOLDEN)
+    lf = rdf.LayeredDecisionForest.load(_write_layered_cfg(tmp_path, g), (60, 84), labels_reduce=2)
+    sib = lf.sibling()
+    assert [m for m, _, _ in sib.m] == [m for m, _, _ in lf.m] and [x[1:] for x in sib.m] == [x[1:] for x in lf.m]
+    assert all(a is not b for a, b in zip(sib.label_images, lf.label_images)) and sib.eval is not lf.eval
+    assert sib.num_layered_classes == lf.num_layered_classes and sib.labels_dims == lf.labels_dims
+    assert np.array_equal(sib.label_colors.cu().get(), lf.label_colors.cu().get())
+    depth, la, lb = rdf.GpuBuffer((60, 84), np.uint16), rdf.GpuBuffer((30, 42), np.uint16), rdf.GpuBuffer((30, 42), np.uint16)
+    depth.cu().set(g["g3_depth"][0])
+    lf.run(depth, la, 1.0)
+    lf.label_images[0].cu().fill(9)        # scribbling over one stack's layer buffers does not reach the other's
+    sib.run(depth, lb, 1.0)
+    assert np.array_equal(lb.cu().get(), g["g3_comp"][0]) and np.array_equal(la.cu().get(), g["g3_comp"][0])
+    assert np.array_equal(sib.label_images[0].cu().get(), g["g3_l0"][0]) and (lf.label_images[0].cu().get() == 9).all()
+
+
 def test_layered_cfg_validation(rdf, host_runtime, tmp_path):
     g = np.load(GOLDEN)
     cfg = json.loads(open(_write_layered_cfg(tmp_path, g)).read())

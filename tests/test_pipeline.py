@@ -97,3 +97,50 @@ def test_hand_pipeline_matches_the_chain_of_restatements(flip_x, rdf, gpu_runtim
     m_c, h_c = pipe.run(dbuf, gbuf, 2, flip_x)
     assert np.array_equal(m_b.view(np.uint64), m_c.view(np.uint64)) and np.array_equal(h_b.view(np.uint64), h_c.view(np.uint64))
     assert not np.array_equal(m_b.view(np.uint64), m_a.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_two_hands_in_flight_together_equal_one_after_the_other(rdf, gpu_runtime):
+    """Two HandPipelines built on ONE LayeredDecisionForest (what the reference app does), captured as two graphs and
+    replayed together on two streams: each pipeline owns the label buffers its graph writes (the second one takes a
+    sibling stack), so the concurrent results equal the sequential ones bit for bit, every time."""
+    import torch
+    pl = importlib.import_module("3d-beats_amd.pipeline")
+    depth, groups = _scene(rdf)
+    f0, f1, conditions, colors = _config(rdf)
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(f0)},
+                      {"model": rdf.DecisionForest.from_numpy(f1), "filter_model": 0, "filter_model_class": 3}],
+           "conditions": conditions, "label_colors": colors}
+    lf = rdf.LayeredDecisionForest(cfg, (H, W), R)
+    args = ((H, W), R, 1.0, 6, np.full(7, 40., np.float32), [3, 4, 5, 6, 7], (421.3, 420.9, 423.1, 238.6),
+            np.eye(4, dtype=np.float32))
+    p1, p2 = pl.HandPipeline(lf, *args), pl.HandPipeline(lf, *args)
+    assert p1.layered_rdf is lf and p2.layered_rdf is not lf
+    assert p2.layered_rdf.m[0][0] is lf.m[0][0]                       # same forest objects (and packed tables)
+    assert p2.layered_rdf.label_images[0] is not lf.label_images[0]   # own label buffers
+    dbuf, gbuf = rdf.GpuBuffer((H, W), np.uint16), rdf.GpuBuffer((H, W), np.uint16)
+    dbuf.cu().set(depth)
+    gbuf.cu().set(groups)
+    want1, want2 = p1.run(dbuf, gbuf, 1, False), p2.run(dbuf, gbuf, 2, True)
+    lab1, lab2 = p1.labels_image.cu().get(), p2.labels_image.cu().get()
+    assert (lab1 != 65535).sum() > 1000 and (lab2 != 65535).sum() > 1000 and not np.array_equal(lab1, lab2)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        r1 = p1.capture(dbuf, gbuf, 1, False)
+    with torch.cuda.stream(s2):
+        r2 = p2.capture(dbuf, gbuf, 2, True)
+    torch.cuda.synchronize()
+    for it in range(25):
+        with torch.cuda.stream(s1):
+            r1(read=False)
+        with torch.cuda.stream(s2):
+            r2(read=False)
+        with torch.cuda.stream(s1):
+            a = r1.read()
+        with torch.cuda.stream(s2):
+            b = r2.read()
+        torch.cuda.synchronize()
+        for got, want in ((a, want1), (b, want2)):
+            assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64)), it
+            assert np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)), it
+        assert np.array_equal(p1.labels_image.cu().get(), lab1) and np.array_equal(p2.labels_image.cu().get(), lab2), it
