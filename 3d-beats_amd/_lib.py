@@ -21,6 +21,9 @@ SIGNATURES = {
     "rdf_layered_run": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                  _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
                                  _c_int, _c_float, _c_void_p]),
+    "rdf_layered_run_hand": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                      _c_int, _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "rdf_forest_packed_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "rdf_forest_pack": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
     "rdf_eval_forest_packed": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
@@ -35,6 +38,7 @@ SIGNATURES = {
     "rdf_setup_depth_image_for_forest": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_stencil_depth_image_by_group": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_flip_x": (_c_int, [_c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_prepare_hand_depth": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
     "rdf_make_rgba_from_labels": (_c_int, [_c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_train_init": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_train_histogram": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
@@ -71,7 +75,6 @@ SIGNATURES = {
     "rdf_set_halo": (None, [_c_int]),
     "rdf_set_lds_levels": (None, [_c_int]),
     "rdf_set_stage_vec": (None, [_c_int]),
-    "rdf_set_blocked": (None, [_c_int]),
     "rdf_set_rows_per_wave": (None, [_c_int]),
     "rdf_set_force_exact": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),

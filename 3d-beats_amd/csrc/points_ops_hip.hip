@@ -79,6 +79,47 @@ __global__ __launch_bounds__(256) void k_rgba(int dim_x, int dim_y, int num_colo
     image[(size_t)y * dim_x + x] = colors[l - 1];
 }
 
+// The app's per-hand input chain in ONE read and ONE write (3d_bz.py:396-420: fill(0) -> stencil_depth_image_by_group ->
+// flip_x or copy -> convert_0s_to_maxuint): out[y][x'] = (group(x, y) == g and d != 0) ? d : 65535, x' = W-1-x when
+// flipping.  One lane = eight consecutive pixels of a row (16 bytes in, 16 bytes out where the row pitch allows).
+__global__ __launch_bounds__(256) void k_prepare_hand(int dim_x, int dim_y, int level, int group, const uint16_t *g_in,
+                                                      const uint16_t *d_in, uint16_t *d_out, int flip, int vec_ok)
+{
+    const int x8 = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = x8 * 8;
+    if (x0 >= dim_x || y >= dim_y) return;
+    const int gw = dim_x >> level, gh = dim_y >> level;
+    const int gy = y >> level;
+    const size_t row = (size_t)y * dim_x;
+    uint32_t v[8];
+    const int n = min(8, dim_x - x0);
+    if (vec_ok && n == 8) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(d_in + row + x0);
+        v[0] = w.x & 0xFFFFu; v[1] = w.x >> 16; v[2] = w.y & 0xFFFFu; v[3] = w.y >> 16;
+        v[4] = w.z & 0xFFFFu; v[5] = w.z >> 16; v[6] = w.w & 0xFFFFu; v[7] = w.w >> 16;
+    } else {
+        for (int k = 0; k < 8; ++k) v[k] = k < n ? d_in[row + x0 + k] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int gx = (x0 + k) >> level;
+        const uint32_t g = (k < n && gx < gw && gy < gh) ? g_in[(size_t)gy * gw + gx] : 0u;   // Array2d::get: 0 out of bounds
+        if ((int)g != group || v[k] == 0u) v[k] = kNoPixel;
+    }
+    if (vec_ok && n == 8) {
+        uint4 o;
+        if (flip) {
+            o = make_uint4(v[7] | (v[6] << 16), v[5] | (v[4] << 16), v[3] | (v[2] << 16), v[1] | (v[0] << 16));
+            *reinterpret_cast<uint4 *>(d_out + row + (dim_x - x0 - 8)) = o;
+        } else {
+            o = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+            *reinterpret_cast<uint4 *>(d_out + row + x0) = o;
+        }
+    } else {
+        for (int k = 0; k < n; ++k) d_out[row + (flip ? dim_x - 1 - (x0 + k) : x0 + k)] = (uint16_t)v[k];
+    }
+}
+
 dim3 grid2d(int dim_x, int dim_y) { return dim3((dim_x + 63) / 64, (dim_y + 3) / 4); }
 
 } // namespace
@@ -114,6 +155,20 @@ int rdf_stencil_depth_image_by_group(int dim_x, int dim_y, int mipmap_level, int
     if (!groups_in || !depth_in || !depth_out) return RDF_ERR_NULL_PTR;
     hipLaunchKernelGGL(k_stencil, grid2d(dim_x, dim_y), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dim_x, dim_y,
                        mipmap_level, group, groups_in, depth_in, depth_out);
+    return (int)hipGetLastError();
+}
+
+int rdf_prepare_hand_depth(int dim_x, int dim_y, int mipmap_level, int group, const uint16_t *groups_in,
+                           const uint16_t *depth_in, uint16_t *depth_out, int flip_x, void *stream)
+{
+    if (dim_x < 0 || dim_y < 0 || mipmap_level < 0 || mipmap_level > 30) return RDF_ERR_BAD_ARG;
+    if (dim_x == 0 || dim_y == 0) return RDF_OK;
+    if (!groups_in || !depth_in || !depth_out) return RDF_ERR_NULL_PTR;
+    if (depth_in == depth_out && flip_x) return RDF_ERR_BAD_ARG;   // a flip in place would read what it has overwritten
+    const int vec_ok = dim_x % 8 == 0 && ((reinterpret_cast<uintptr_t>(depth_in) | reinterpret_cast<uintptr_t>(depth_out)) & 15u) == 0;
+    hipLaunchKernelGGL(k_prepare_hand, dim3((dim_x + 511) / 512, (dim_y + 3) / 4), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), dim_x, dim_y, mipmap_level, group, groups_in, depth_in,
+                       depth_out, flip_x ? 1 : 0, vec_ok);
     return (int)hipGetLastError();
 }
 

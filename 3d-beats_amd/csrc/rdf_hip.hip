@@ -48,7 +48,8 @@ namespace {
 constexpr int kGroup = 4;          // trees walked interleaved by one lane (template GROUP: 1 and 2 for smaller forests)
 constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
 constexpr int kDefaultLdsBudget = 32700;   // node table + depth tile per workgroup
-constexpr int kDefaultHalo = 24;   // depth pixels staged around a tile's centres
+constexpr int kDefaultHalo = 32;   // depth pixels staged around a tile's centres
+constexpr int kMinLdsLevels = 6;   // top levels of every tree that stay in LDS when the depth tile competes for it
 constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
 constexpr int kSchedSlots = 256;        // one per (device, stream) that launches directly
 constexpr int kGraphSlots = 768;        // one per launch recorded into a hipGraph (stream capture)
@@ -77,36 +78,6 @@ __device__ unsigned int g_sched[kSchedSlots + kGraphSlots][2];
 // tools/verify_payload.hip (1.2e14, 2.1e14 and 1.4e14 cases, 0 mismatches; logs under profiles/).  Any other
 // numerator (huge, denormal, inf, NaN) flags the node kFlagExact and the kernel takes the IEEE divide on the
 // fp32 values of the exact record.
-// ---- deep levels: subtree-blocked copy of the hot records --------------------------------------
-// The heap order of the reference (cu_utils.hpp:32-39) puts a node's children 2^j records away: below the levels that
-// stay resident in L2 every level of a lane's walk is another 128-byte line from the Infinity Cache or HBM.  The packed
-// table therefore holds the hot records of levels >= k0 a second time, grouped into 3-level subtrees: the root at
-// level k0 + 3b, its two children and four grandchildren are records 0, 1-2, 3-6 of ONE aligned 128-byte line (the
-// eighth slot is unused), so three levels of a walk cost one line from beyond L2 instead of three.  k0 is 4, 5 or 6,
-// whichever makes (D - k0) a multiple of 3, so that the last block is full; block level b of a tree starts at byte
-// 128 * 2^k0 * (8^b - 1) / 7.  Forests with D < 7 have no blocked table (k0 = D).
-__host__ __device__ inline int blocked_k0(int D) { return D >= 7 ? 4 + (D - 4) % 3 : D; }
-__host__ __device__ inline size_t blocked_level_offset(int k0, int b)
-{
-    size_t n = 0, w = (size_t)1 << k0;
-    for (int i = 0; i < b; ++i, w <<= 3) n += w;
-    return n * 128u;
-}
-__host__ __device__ inline size_t blocked_tree_bytes(int D)
-{
-    const int k0 = blocked_k0(D);
-    return blocked_level_offset(k0, (D - k0) / 3);
-}
-// byte offset of heap node h (1-based, level j >= k0) inside its tree's blocked table
-__host__ __device__ inline size_t blocked_node_offset(int k0, int j, size_t h)
-{
-    const int b = (j - k0) / 3, t = (j - k0) - 3 * b;
-    const size_t root = h >> t;                                   // ancestor on the block's root level j - t
-    const size_t r = root - ((size_t)1 << (j - t));               // its index on that level
-    const size_t p = (((size_t)1 << t) - 1) + (h & (((size_t)1 << t) - 1));
-    return blocked_level_offset(k0, b) + r * 128u + p * 16u;
-}
-
 struct alignas(16) NodeRec16 {
     uint32_t w[4];
 };
@@ -145,10 +116,6 @@ struct EvalArgs {
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
-    const char *blocked;       // hot records of levels >= blk_k0 again, as 3-level subtrees of 7 records in one 128-byte line
-    uint32_t blk_tree_bytes;   // bytes of one tree's blocked table
-    int blk_k0;                // first blocked level (>= D: no blocked table); (D - blk_k0) % 3 == 0
-    uint32_t blk_off[9];       // byte offset of block level b = levels blk_k0 + 3b .. + 2 inside a tree's table
     int cpad;                  // classes rounded up to a multiple of 4
     int filter_class;
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
@@ -474,22 +441,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                                 const uint32_t tk = (uint32_t)min(kb + k, a.T - 1);   // wave-uniform
                                 n[k] = decode_node(lds_nodes[tk * lds_pitch + hn[k]]);
                             }
-                        } else if (PACKED && j >= a.blk_k0) {
-                            // subtree-blocked table: (root of the 3-level block) * 128 + (place inside the block) * 16.
-                            // j is wave-uniform, so the block level, the depth t inside the block and every constant
-                            // below live in scalar registers; the 2^(j-t) that turns the root's heap index into its
-                            // index on its level is folded into the scalar base (mod 2^32: offsets stay below 2^32).
-                            const int jj = j - a.blk_k0;
-                            const int bl = jj / 3, t = jj - 3 * bl;
-                            const uint32_t mask = (1u << t) - 1u;
-                            const uint32_t sbase = a.blk_off[bl] - ((1u << (j - t)) << 7) + (mask << 4);
-#pragma unroll
-                            for (int k = 0; k < GROUP; ++k) {
-                                const int tk = min(kb + k, a.T - 1);
-                                const char *base = a.blocked + (size_t)tk * a.blk_tree_bytes;
-                                const uint32_t off = sbase + ((hn[k] >> t) << 7) + ((hn[k] & mask) << 4);
-                                n[k] = decode_node(*reinterpret_cast<const uint4 *>(base + off));
-                            }
                         } else if (PACKED) {
 #pragma unroll
                             for (int k = 0; k < GROUP; ++k) {
@@ -672,7 +623,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 
 // ---- load-time repack: one thread per node; writes the 16-byte and the 32-byte table ----
 __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, NodeRec32 *packed32,
-                                              float *packed_pdf, char *blocked, int C, int cpad,
+                                              float *packed_pdf, int C, int cpad,
                                               size_t total_slots, int D, int E, float s, int force_exact)
 {
     // slot = tree * 2^D + h, h = 1-based heap index (slot h == 0 of each tree is unused and zeroed)
@@ -698,16 +649,6 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     n.pad0 = n.pad1 = 0;
     packed16[slot] = h16;
     packed32[slot] = n;
-    const int k0 = blocked_k0(D), lvl = 63 - __clzll((unsigned long long)h);
-    if (lvl >= k0) {
-        char *bt = blocked + tree * blocked_tree_bytes(D);
-        const size_t off = blocked_node_offset(k0, lvl, h);
-        *reinterpret_cast<NodeRec16 *>(bt + off) = h16;
-        if ((off & 127u) == 0u) {   // the block's root also clears the unused eighth slot
-            NodeRec16 z16 = {{0u, 0u, 0u, 0u}};
-            *reinterpret_cast<NodeRec16 *>(bt + off + 112u) = z16;
-        }
-    }
     float *q = packed_pdf + slot * 2 * (size_t)cpad;   // [left: cpad][right: cpad], the PDFs as stored (row N of SURVEY 8a)
     for (int c = 0; c < cpad; ++c) {
         q[c] = c < C ? p[7 + c] : 0.f;
@@ -716,12 +657,22 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
 }
 
 // ---- composite (tree_eval.cu:214-248): one lane per label pixel ----
+// Optional extras of the app's per-hand chain folded into the store (3d_bz.py:440-456): the composite is written
+// mirrored in x (`flip_w` = label row width, 0 = as is; the app flips the left hand's labels back) and the label's
+// colour goes to an RGBA image at the same place (make_rgba_from_labels, points_ops.cu:258-281: labels 0, 65535 and
+// > num_colors leave the texel alone).
 __global__ __launch_bounds__(256) void k_composite(const uint16_t *const *imgs, int n_images, uint32_t n_px,
                                                    const int2 *cond, int n_cond, uint16_t *out, int32_t *bad,
-                                                   int fill_untouched)
+                                                   int fill_untouched, uint32_t flip_w, const uint32_t *colors,
+                                                   int num_colors, uint32_t *rgba)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_px) return;
+    uint32_t q = p;
+    if (flip_w) {
+        const uint32_t y = p / flip_w, x = p - y * flip_w;
+        q = y * flip_w + (flip_w - 1u - x);
+    }
     long long off = 0;
     bool invalid = true;   // fell off the last image (tree_eval.cu:246-247)
     for (int i = 0; i < n_images; ++i) {
@@ -731,13 +682,15 @@ __global__ __launch_bounds__(256) void k_composite(const uint16_t *const *imgs, 
         if (e < 0 || e >= n_cond) break;
         const int2 tv = cond[e];
         if (tv.x == 0) {
-            out[p] = (uint16_t)tv.y;
+            const uint32_t v = (uint32_t)(uint16_t)tv.y;
+            out[q] = (uint16_t)v;
+            if (rgba && v != 0u && v != kNoPixel && v <= (uint32_t)num_colors) rgba[q] = colors[v - 1u];
             return;
         }
         off = tv.y;
     }
     if (invalid && bad) atomicAdd(bad, 1);
-    if (fill_untouched) out[p] = (uint16_t)kNoPixel;
+    if (fill_untouched) out[q] = (uint16_t)kNoPixel;
 }
 
 __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *dst, size_t n, uint16_t v)
@@ -1008,7 +961,6 @@ int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void 
 
 int g_halo = -1;
 int g_lds_levels = -1;
-int g_blocked = -1;
 int g_stage_vec = -1;
 int g_rows_per_wave = 0;
 int g_force_exact = 0;
@@ -1046,13 +998,6 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         a.packed32 = reinterpret_cast<const NodeRec32 *>(a.packed16 + slots);
         a.packed_pdf = reinterpret_cast<const float *>(a.packed32 + slots);
         a.cpad = (n_classes + 3) & ~3;
-        a.blocked = reinterpret_cast<const char *>(a.packed_pdf + slots * 2 * (size_t)a.cpad);
-        a.blk_tree_bytes = (uint32_t)blocked_tree_bytes(max_depth);
-        const int use_blocked = g_blocked >= 0 ? g_blocked : env_int("RDF_BLOCKED", 1);
-        a.blk_k0 = use_blocked ? blocked_k0(max_depth) : max_depth;
-        for (int b = 0; b < 9; ++b) a.blk_off[b] = (uint32_t)blocked_level_offset(blocked_k0(max_depth), b < 8 ? b : 8);
-    } else {
-        a.blk_k0 = max_depth;
     }
 
     int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
@@ -1075,10 +1020,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
 
     // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B][pixel list] ----
     const long long budget = lds_budget();
-    // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>): two pixels
-    // less halo keep five workgroups per CU
+    // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
     const bool compact_launch = block == 256 && !stats && filter_class != -1 && g_compaction != 0;
-    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", compact_launch ? kDefaultHalo - 2 : kDefaultHalo);
+    // forests of eight and more trees trade one more LDS level for eight more pixels of halo (config 5's shape, T8/D22:
+    // 6 levels + 32 px 12.90 ms, 5 levels + 40 px 12.68 ms; four trees: 7 + 32 5.17 ms, 6 + 40 5.61 ms)
+    const bool many_trees = n_trees >= 8;
+    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", many_trees ? kDefaultHalo + 8 : kDefaultHalo);
     long long tile_bytes = 0;
     // The staged tile may take half the budget.  With labels_reduce > 1 a tile spans r times the pixels per label, so
     // the halo shrinks (by twos) until the tile fits -- a narrow tile still beats none: 64 frames at r = 2 take 1.08 ms
@@ -1093,8 +1040,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     int k_forced = g_lds_levels >= 0 ? g_lds_levels : env_int("RDF_LDS_LEVELS", -1);
     if (k_forced > max_depth) k_forced = max_depth;
     while (k_forced > 0 && (long long)n_trees * (1ll << k_forced) * 16 + 32 + list_bytes > budget) --k_forced;
-    const long long tile_budget = k_forced >= 0 ? budget - 32 - list_bytes - (k_forced > 0 ? (long long)n_trees * (1ll << k_forced) * 16 : 0)
-                                                : budget / 2;
+    // otherwise the tile may take what kMinLdsLevels levels of the forest leave: level for level, a level moved from LDS
+    // to L1-resident global records costs less than the far probes a wider halo saves (measured: T4, 8 levels + 24 px
+    // 5.26 ms, 7 levels + 32 px 5.17 ms, 6 levels + 40 px 5.6 ms on the bench batch)
+    const int k_min = many_trees ? kMinLdsLevels - 1 : kMinLdsLevels;
+    const int k_floor = k_forced >= 0 ? k_forced : (max_depth < k_min ? max_depth : k_min);
+    const long long tile_budget = budget - 32 - list_bytes - (k_floor > 0 ? (long long)n_trees * (1ll << k_floor) * 16 : 0);
     // 16-byte staging needs every row start 16-byte aligned in the image and in LDS
     const int want_vec = g_stage_vec >= 0 ? g_stage_vec : env_int("RDF_STAGE_VEC", 1);
     const bool vec_ok = want_vec && dim_x % 8 == 0 && ((64 * r) % 8 == 0) && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0;
@@ -1173,8 +1124,7 @@ size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes)
 {
     if (n_trees < 0 || max_depth < 0 || max_depth > 30 || n_classes < 0) return 0;
     return ((size_t)n_trees << max_depth) *
-               (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float)) +
-           (size_t)n_trees * blocked_tree_bytes(max_depth);
+           (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float));
 }
 
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes, float scale_factor,
@@ -1191,8 +1141,6 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
                        forest, reinterpret_cast<NodeRec16 *>(packed),
                        reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total),
                        reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32))),
-                       reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32) +
-                                                                   2 * (size_t)classes_padded(n_classes) * sizeof(float)),
                        n_classes, classes_padded(n_classes), total,
                        max_depth, 7 + 2 * n_classes, scale_factor, g_force_exact);
     return (int)hipGetLastError();
@@ -1224,16 +1172,16 @@ int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, 
     const unsigned blocks = (unsigned)((n_px + 255) / 256);
     hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        label_images, n_images, (uint32_t)n_px, reinterpret_cast<const int2 *>(cond), n_cond, out,
-                       bad_count, 0);
+                       bad_count, 0, 0u, nullptr, 0, nullptr);
     return (int)hipGetLastError();
 }
 
-int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers, const void *const *packed,
-                    const float *const *forests, const int *n_trees, const int *max_depth, const int *n_classes,
-                    const int *filter_layer, const int *filter_class, uint16_t *const *layer_labels,
-                    const uint16_t *const *layer_labels_dev_table, const int32_t *cond, int n_cond,
-                    uint16_t *composite_out, int32_t *bad_count, int labels_reduce, float scale_factor,
-                    void *stream)
+static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers, const void *const *packed,
+                       const float *const *forests, const int *n_trees, const int *max_depth, const int *n_classes,
+                       const int *filter_layer, const int *filter_class, uint16_t *const *layer_labels,
+                       const uint16_t *const *layer_labels_dev_table, const int32_t *cond, int n_cond,
+                       uint16_t *composite_out, int32_t *bad_count, int labels_reduce, float scale_factor,
+                       int flip_x, const uint8_t *colors_rgba, int num_colors, uint8_t *image_rgba, void *stream)
 {
     if (n_layers < 0 || dim_x < 0 || dim_y < 0 || labels_reduce < 1 || n_cond < 0) return RDF_ERR_BAD_ARG;
     if (n_layers > 0 && (!forests || !n_trees || !max_depth || !n_classes || !filter_layer || !filter_class ||
@@ -1260,8 +1208,34 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers, c
     const unsigned blocks = (unsigned)((n_px + 255) / 256);
     hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        layer_labels_dev_table, n_layers, (uint32_t)n_px, reinterpret_cast<const int2 *>(cond), n_cond,
-                       composite_out, bad_count, 1);
+                       composite_out, bad_count, 1, flip_x ? (uint32_t)lw : 0u,
+                       reinterpret_cast<const uint32_t *>(colors_rgba), num_colors, reinterpret_cast<uint32_t *>(image_rgba));
     return (int)hipGetLastError();
+}
+
+int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers, const void *const *packed,
+                    const float *const *forests, const int *n_trees, const int *max_depth, const int *n_classes,
+                    const int *filter_layer, const int *filter_class, uint16_t *const *layer_labels,
+                    const uint16_t *const *layer_labels_dev_table, const int32_t *cond, int n_cond,
+                    uint16_t *composite_out, int32_t *bad_count, int labels_reduce, float scale_factor,
+                    void *stream)
+{
+    return layered_run(depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes, filter_layer,
+                       filter_class, layer_labels, layer_labels_dev_table, cond, n_cond, composite_out, bad_count,
+                       labels_reduce, scale_factor, 0, nullptr, 0, nullptr, stream);
+}
+
+int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_layers, const void *const *packed,
+                         const float *const *forests, const int *n_trees, const int *max_depth, const int *n_classes,
+                         const int *filter_layer, const int *filter_class, uint16_t *const *layer_labels,
+                         const uint16_t *const *layer_labels_dev_table, const int32_t *cond, int n_cond,
+                         uint16_t *composite_out, int32_t *bad_count, int labels_reduce, float scale_factor,
+                         int flip_x, const uint8_t *colors_rgba, int num_colors, uint8_t *image_rgba, void *stream)
+{
+    if (num_colors < 0 || (image_rgba && num_colors > 0 && !colors_rgba)) return RDF_ERR_BAD_ARG;
+    return layered_run(depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes, filter_layer,
+                       filter_class, layer_labels, layer_labels_dev_table, cond, n_cond, composite_out, bad_count,
+                       labels_reduce, scale_factor, flip_x, colors_rgba, num_colors, image_rgba, stream);
 }
 
 int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream)
@@ -1299,7 +1273,6 @@ void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
 void rdf_set_compaction(int mode) { g_compaction = mode; }
 void rdf_set_halo(int pixels) { g_halo = pixels; }
 void rdf_set_lds_levels(int levels) { g_lds_levels = levels; }
-void rdf_set_blocked(int on) { g_blocked = on; }
 void rdf_set_stage_vec(int on) { g_stage_vec = on; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }

@@ -36,6 +36,14 @@ class PointsOps:
                                                             device_ptr(d_in), device_ptr(d_out), self._rt.stream()),
                  "rdf_stencil_depth_image_by_group", d_out)
 
+    def prepare_hand_depth(self, img_dim, mipmap_level, group, g_in, d_in, d_out, flip_x):
+        """fill(0) + stencil_depth_image_by_group + flip_x (or copy) + convert_0s_to_maxuint of 3d_bz.py:396-420 as one
+        pass: d_out = the frame as the forest wants it for this hand.  No reference counterpart as a single kernel."""
+        dim_x, dim_y = (int(v) for v in np.asarray(img_dim).reshape(-1)[:2])
+        self._ok(self._lib.rdf_prepare_hand_depth(dim_x, dim_y, int(mipmap_level), int(group), device_ptr(g_in),
+                                                  device_ptr(d_in), device_ptr(d_out), 1 if flip_x else 0, self._rt.stream()),
+                 "rdf_prepare_hand_depth", d_out)
+
     def flip_x(self, img_dim, img_in, img_out, grid=None, block=None):
         dim_x, dim_y = (int(v) for v in np.asarray(img_dim).reshape(-1)[:2])
         self._ok(self._lib.rdf_flip_x(dim_x, dim_y, device_ptr(img_in), device_ptr(img_out), self._rt.stream()),

@@ -204,7 +204,29 @@ class LayeredDecisionForest:
         self.eval.make_composite_labels_image(self.labels_images_ptrs_cu.cu(), self.labels_dims[1], self.labels_dims[0],
                                               self.labels_conditions_cu.cu(), labels_image.cu().reshape(label_shape))
 
-    def _run_fused(self, depth_image, labels_image, scale_factor):
+    def run_hand(self, depth_image, labels_image, scale_factor=1., flip_x=False, color_image=None):
+        """run() plus what the app does with one hand's composite (3d_bz.py:440-456) inside the same call: the composite
+        is stored mirrored in x when `flip_x` (the left hand's labels go back to camera orientation) and `color_image`
+        (RGBA bytes, labels_dims + (4,)) receives label_colors[label - 1] wherever a label in 1..num_layered_classes is
+        written, as make_rgba_from_labels would.  The per-layer label images stay unflipped.  Stacks that cannot take the
+        fused call (a layer filtering on a later layer) run the reference sequence followed by the separate kernels."""
+        if self.fused:
+            return self._run_fused(depth_image, labels_image, scale_factor, bool(flip_x), color_image)
+        from .cuda.points_ops import PointsOps
+        po = PointsOps()
+        ldims = np.array([self.labels_dims[1], self.labels_dims[0]], dtype=np.int32)
+        if flip_x:
+            tmp = GpuBuffer(self.labels_dims, dtype=np.uint16)
+            self.run(depth_image, tmp, scale_factor)
+            po.flip_x(ldims, tmp.cu(), labels_image.cu())
+        else:
+            self.run(depth_image, labels_image, scale_factor)
+        if color_image is not None:
+            po.make_rgba_from_labels(np.uint32(self.labels_dims[1]), np.uint32(self.labels_dims[0]),
+                                     np.uint32(self.num_layered_classes), labels_image.cu(), self.label_colors.cu(),
+                                     color_image.cu())
+
+    def _run_fused(self, depth_image, labels_image, scale_factor, flip_x=False, color_image=None):
         """Same result through ONE C-ABI call (rdf_layered_run): the three fills are fused into the kernels."""
         import ctypes
         n = self.num_models
@@ -224,14 +246,22 @@ class LayeredDecisionForest:
             tabs = [m.packed(scale_factor) if m.max_depth <= 27 else None for m, _, _ in self.m]
             packed = fa["vp"](*[t.ptr if t is not None else None for t in tabs])
         ev = self.eval
-        rc = ev._lib.rdf_layered_run(device_ptr(depth_image), int(self.depth_dims[1]), int(self.depth_dims[0]), n,
-                                     packed, fa["forests"], fa["n_trees"], fa["max_depth"], fa["n_classes"],
-                                     fa["filter_layer"], fa["filter_class"], fa["layer_labels"],
-                                     device_ptr(self.labels_images_ptrs_cu), device_ptr(self.labels_conditions_cu),
-                                     int(self.labels_conditions_cu.shape[0]), device_ptr(labels_image),
-                                     ev._composite_bad.ptr, int(self.labels_reduce), float(scale_factor),
-                                     ev._rt.stream())
-        _lib.check(ev._lib, rc, "rdf_layered_run")
+        common = (device_ptr(depth_image), int(self.depth_dims[1]), int(self.depth_dims[0]), n,
+                  packed, fa["forests"], fa["n_trees"], fa["max_depth"], fa["n_classes"],
+                  fa["filter_layer"], fa["filter_class"], fa["layer_labels"],
+                  device_ptr(self.labels_images_ptrs_cu), device_ptr(self.labels_conditions_cu),
+                  int(self.labels_conditions_cu.shape[0]), device_ptr(labels_image),
+                  ev._composite_bad.ptr, int(self.labels_reduce), float(scale_factor))
+        if flip_x or color_image is not None:
+            rc = ev._lib.rdf_layered_run_hand(*common, 1 if flip_x else 0, device_ptr(self.label_colors),
+                                              int(self.num_layered_classes),
+                                              device_ptr(color_image) if color_image is not None else None, ev._rt.stream())
+            _lib.check(ev._lib, rc, "rdf_layered_run_hand")
+            if color_image is not None:
+                _touch(color_image.cu())
+        else:
+            rc = ev._lib.rdf_layered_run(*common, ev._rt.stream())
+            _lib.check(ev._lib, rc, "rdf_layered_run")
         for b in self.label_images:
             _touch(b.cu())
         _touch(labels_image.cu())

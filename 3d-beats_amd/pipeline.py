@@ -20,7 +20,7 @@ from .engine.buffer import GpuBuffer
 
 class HandPipeline:
     def __init__(self, layered_rdf, depth_dims, labels_reduce, eval_to_train_dim_ratio, mean_shift_rounds,
-                 mean_shift_variances, fingertip_idxes, intrinsics, plane, depth_mm_level=0):
+                 mean_shift_variances, fingertip_idxes, intrinsics, plane, depth_mm_level=0, fused_io=True):
         """depth_dims = (DIM_Y, DIM_X); intrinsics = (fx, fy, ppx, ppy) of the depth stream; plane = the calibrated
         plane's 4x4 matrix (calibrated_plane.plane); fingertip_idxes = 1-based composite label ids (3d_bz.py:112)."""
         self._rt = get_runtime()
@@ -38,6 +38,7 @@ class HandPipeline:
         self.LABELS_DIM_Y, self.LABELS_DIM_X = self.DIM_Y // self.LABELS_REDUCE, self.DIM_X // self.LABELS_REDUCE
         self.EVAL_TO_TRAIN_DIM_RATIO = float(eval_to_train_dim_ratio)
         self.depth_mm_level = int(depth_mm_level)
+        self.fused_io = bool(fused_io)   # False: the reference's nine launches around the forest, one by one
         self.mean_shift_rounds = int(mean_shift_rounds)
         self.fingertip_idxes = [int(i) for i in fingertip_idxes]
         self.intrinsics = tuple(float(v) for v in intrinsics)
@@ -96,22 +97,31 @@ class HandPipeline:
         dims = np.array([self.DIM_X, self.DIM_Y], dtype=np.int32)
         ldims = np.array([self.LABELS_DIM_X, self.LABELS_DIM_Y], dtype=np.int32)
         po = self.points_ops
-        self.depth_image_group.cu().fill(0)
-        po.stencil_depth_image_by_group(dims, np.int32(self.depth_mm_level), np.int32(g_id), depth_image_mm_groups.cu(),
-                                        depth_image.cu(), self.depth_image_group.cu())
-        if flip_x:
-            po.flip_x(dims, self.depth_image_group.cu(), self.depth_image_2.cu())
+        if self.fused_io:
+            # one pass in, none out: the stencil, the flip and 0 -> 65535 are one kernel, the flip back and the colouring
+            # ride on the composite kernel's store (rdf_prepare_hand_depth, rdf_layered_run_hand)
+            po.prepare_hand_depth(dims, np.int32(self.depth_mm_level), np.int32(g_id), depth_image_mm_groups.cu(),
+                                  depth_image.cu(), self.depth_image_2.cu(), flip_x)
+            self.layered_rdf.run_hand(self.depth_image_2, self.labels_image, self.EVAL_TO_TRAIN_DIM_RATIO, flip_x,
+                                      self.labels_image_rgba)
         else:
-            self.depth_image_2.cu().copy_from(self.depth_image_group.cu())
-        po.convert_0s_to_maxuint(np.int32(self.DIM_X * self.DIM_Y), self.depth_image_2.cu())
+            # the reference's sequence, kernel for kernel (3d_bz.py:396-456)
+            self.depth_image_group.cu().fill(0)
+            po.stencil_depth_image_by_group(dims, np.int32(self.depth_mm_level), np.int32(g_id), depth_image_mm_groups.cu(),
+                                            depth_image.cu(), self.depth_image_group.cu())
+            if flip_x:
+                po.flip_x(dims, self.depth_image_group.cu(), self.depth_image_2.cu())
+            else:
+                self.depth_image_2.cu().copy_from(self.depth_image_group.cu())
+            po.convert_0s_to_maxuint(np.int32(self.DIM_X * self.DIM_Y), self.depth_image_2.cu())
 
-        self.layered_rdf.run(self.depth_image_2, self.labels_image, self.EVAL_TO_TRAIN_DIM_RATIO)
+            self.layered_rdf.run(self.depth_image_2, self.labels_image, self.EVAL_TO_TRAIN_DIM_RATIO)
 
-        if flip_x:
-            self.labels_image_2.cu().copy_from(self.labels_image.cu())
-            po.flip_x(ldims, self.labels_image_2.cu(), self.labels_image.cu())
-        po.make_rgba_from_labels(np.uint32(self.LABELS_DIM_X), np.uint32(self.LABELS_DIM_Y), np.uint32(self._L),
-                                 self.labels_image.cu(), self.layered_rdf.label_colors.cu(), self.labels_image_rgba.cu())
+            if flip_x:
+                self.labels_image_2.cu().copy_from(self.labels_image.cu())
+                po.flip_x(ldims, self.labels_image_2.cu(), self.labels_image.cu())
+            po.make_rgba_from_labels(np.uint32(self.LABELS_DIM_X), np.uint32(self.LABELS_DIM_Y), np.uint32(self._L),
+                                     self.labels_image.cu(), self.layered_rdf.label_colors.cu(), self.labels_image_rgba.cu())
 
         means = self.mean_shift.run_device(self.mean_shift_rounds,
                                            self.labels_image.cu().reshape((1, self.LABELS_DIM_Y, self.LABELS_DIM_X)),

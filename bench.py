@@ -6,17 +6,24 @@ One "step" = one pass of the forest kernel over this rank's batch of synthetic 8
 Default workload: 128 frames per GPU per step (= config 4's shard, 1024 frames / 8 GPUs; it is
 config 2's frame x 128, half dense / half live-like), weak scaling: N GPUs evaluate N x 128 frames
 and every rank's label maps reach rank 0 over xGMI inside the timed region (copy-engine peer copies into rank 0's
-IPC-mapped buffer by default, an RCCL gather as the fallback: DESIGN.md section 6).  Config 2 itself
-(ONE 848x480 frame per launch) is measured in the same run and reported as `cfg2_single_frame`.
+IPC-mapped buffer by default, an RCCL gather as the fallback: DESIGN.md section 6).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `cpu_baseline` is this repo's CPU restatement (oracle/rdf_oracle.c,
-OpenMP) -- the reference has no CPU path -- timed on a bounded sample of the same frames.
+Rank 0 prints ONE JSON line.  At N = 1 the same run also measures
+  * `cfg2_single_frame` (ONE 848x480 frame per launch), `cfg3_layered_run` (LayeredDecisionForest.run),
+  * `cfg5_shard` (config 5's per-GPU shard: 32 dense 1280x720 frames, 8 trees of depth 22, two frames checked against
+    the oracle inside the run),
+  * `roofline` objects for the headline kernel, config 2 and config 5: a hierarchical roofline (tools/roofline.py) built
+    from rocprofv3 counters that THIS run collects -- before it touches the GPU itself it starts itself once per counter
+    set as `rocprofv3 --pmc ... -- python3 bench.py --leg <name>` (separate passes, never combined with tracing),
+  * `cpu_baseline`: this repo's CPU restatement (oracle/rdf_oracle.c, OpenMP) -- the reference has no CPU path --
+    timed on a bounded sample of the same frames, which also checks the GPU labels of those frames bit for bit.
 """
 import argparse
+import contextlib
 import importlib
 import json
 import os
@@ -28,8 +35,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CACHE = os.environ.get("RDF_BENCH_CACHE", "/tmp/rdf_bench_cache")
 
 
 def parse():
@@ -47,20 +55,27 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="eval/gather pipeline chunks per step (0: one launch per step; at N>1 the gather then overlaps the NEXT step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline levels "
+                    "then come from the committed profiles/r02_roofline_counters.json and say so)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the config-5 shard leg (2 GiB forest)")
+    ap.add_argument("--cfg5-frames", type=int, default=32)
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer variant (pinned H2D + kernel + D2H)")
-    ap.add_argument("--headline-only", action="store_true", help="only the timed batch (no cfg2/cfg3/PCIe/CPU legs): "
+    ap.add_argument("--headline-only", action="store_true", help="only the timed batch (no other legs, no counters): "
                     "what tools/profile.sh traces so that rocprofv3's per-kernel average is the headline kernel's")
+    ap.add_argument("--leg", default=None, choices=["headline", "cfg2", "cfg5"],
+                    help="internal: run ONE leg and print its kernel time (the program the --pmc passes profile)")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
     ap.add_argument("--scheduler", default="dynamic", choices=["dynamic", "static", "tile"],
                     help="tile schedule of the forest kernel: persistent workgroups on a device-side queue (default), "
                          "persistent with static striding, or one workgroup per tile (non-persistent: 8 %% slower alone, "
                          "but a concurrent RCCL kernel never waits for a free slot)")
-    ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl"],
+    ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl", "both"],
                     help="how the label maps reach rank 0 at N>1: p2p = every rank copies its shard into rank 0's "
                          "IPC-mapped buffer with the copy engines (no CU involved); rccl = torch.distributed.gather on a "
-                         "compute stream that leaves 32 CUs to RCCL; auto = p2p if the buffer can be mapped, else rccl")
+                         "compute stream that leaves 32 CUs to RCCL; auto = p2p if the buffer can be mapped, else rccl; "
+                         "both = time p2p and rccl back to back (`value` is p2p's, `gather_modes` carries both)")
     ap.add_argument("--reserve-cus", type=int, default=-1, help="run the forest kernel on a stream that leaves this many CUs "
-                    "(one per shader engine = 32) to RCCL's kernels; -1: 32 at N>1, 0 at N=1 (DESIGN.md section 6)")
+                    "(one per shader engine = 32) to RCCL's kernels; -1: 32 with the rccl gather, 0 otherwise (DESIGN.md section 6)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
                     "rehearse the control flow with several ranks on one GPU)")
     return ap.parse_args()
@@ -104,24 +119,84 @@ def host_cores():
     return max(1, n)
 
 
-def load_traffic(key):
-    """HBM bytes per launch from a committed PMC run (profiles/roofline_traffic.json), or None."""
-    p = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+def cached(name, make):
+    """Synthetic inputs are seeded and deterministic; the --pmc child passes reuse what the first process generated."""
+    path = os.path.join(CACHE, name + ".npy")
     try:
-        return json.load(open(p)).get(key, {}).get("hbm_bytes_per_launch")
+        return np.load(path, mmap_mode="r")
+    except Exception:
+        pass
+    arr = make()
+    try:
+        os.makedirs(CACHE, exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp.npy"
+        np.save(tmp, arr)
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return arr
+
+
+def committed_counters(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_counters.json"))).get(key)
     except Exception:
         return None
+
+
+def collect_counters(a, legs):
+    """Separate `rocprofv3 --pmc` passes over `python3 bench.py --leg X` (this very file), one process per pass, started
+    before this process initialises HIP.  Returns {leg: {"counters":…, "kernel":…, "kernel_ms_profiled":…, "source":…}}."""
+    import roofline
+    out = {}
+    shape = ["--frames", str(a.frames), "--height", str(a.height), "--width", str(a.width), "--trees", str(a.trees),
+             "--depth", str(a.depth), "--classes", str(a.classes), "--topology", a.topology, "--scheduler", a.scheduler,
+             "--cfg5-frames", str(a.cfg5_frames)] + (["--unpacked"] if a.unpacked else [])
+    for leg in legs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--steps", "3", "--warmup", "1"] + shape
+        t0 = time.perf_counter()
+        name, vals, log = roofline.collect(cmd, "k_eval_forest", timeout=300, passes=roofline.PASSES)
+        out[leg] = {"counters": vals, "kernel": name, "log": log, "seconds": round(time.perf_counter() - t0, 1),
+                    "source": "rocprofv3 --pmc child passes of this run" if vals else None}
+    return out
+
+
+def roofline_for(leg, key, live, kernel_ms, alg_bytes):
+    import roofline
+    c = (live or {}).get(leg, {})
+    vals, src, kern = c.get("counters"), c.get("source"), c.get("kernel")
+    if not vals:
+        com = committed_counters(key)
+        if com:
+            vals, kern = com.get("counters"), com.get("kernel")
+            src = "profiles/r02_roofline_counters.json (committed; this run collected none)"
+    r = roofline.model(vals, kernel_ms, alg_bytes)
+    r["kernel"] = kern or "k_eval_forest"
+    r["counters_source"] = src
+    r["counters"] = {k: (int(v) if v == int(v) else round(v, 1)) for k, v in (vals or {}).items() if not k.startswith("_")}
+    return r
 
 
 def main():
     a = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL, peer-mapped buffers); before HIP starts
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    full_run = world == 1 and a.leg is None and not a.headline_only
+
+    # ---- counters first: the child passes must run before this process touches the GPU ----
+    live = None
+    if full_run and not a.no_counters:
+        legs = ["headline", "cfg2"] + ([] if a.no_cfg5 else ["cfg5"])
+        try:
+            live = collect_counters(a, legs)
+        except Exception as e:   # never let the profiler take the measurement down
+            print(f"counter collection failed: {type(e).__name__}: {e}", file=sys.stderr)
+
+    import torch
+    import torch.distributed as dist
+
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N (N>1) must be launched with torch.distributed.run --nproc-per-node N")
@@ -130,7 +205,6 @@ def main():
     torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
@@ -141,17 +215,103 @@ def main():
     synth = rdf.synth
     rt = rdf.get_runtime()  # raises without the HIP library or a device: no CPU fallback
     lib = rt.lib
+    lib.rdf_set_scheduler({"dynamic": 1, "static": 0, "tile": 2}[a.scheduler])
+    ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ================================================================================================================
+    # config 5's per-GPU shard: dense 1280x720 frames, T8/D22/C4 full forest (512 MB of hot records: beyond the 256-MB
+    # Infinity Cache), one launch per step; two frames compared with the oracle
+    # ================================================================================================================
+    def leg_cfg5(steps, warmup, check):
+        F5, H5, W5, T5, D5, C5 = a.cfg5_frames, 720, 1280, 8, 22, 4
+        f_np = cached(f"forest_T{T5}_D{D5}_C{C5}_full", lambda: synth.forest(T5, D5, C5, "full"))
+        fr_np = cached(f"frames_dense_{F5}_{H5}x{W5}_at5000", lambda: synth.frames(["dense"] * F5, 5000, H5, W5))
+        forest5 = rdf.DecisionForest.from_numpy(np.asarray(f_np))
+        depth5 = rdf.to_device(np.asarray(fr_np))
+        lab5 = rdf.DeviceArray((F5, H5, W5), np.uint16).fill(65535)
+        if not a.unpacked:
+            forest5.packed(1.0)
+        for _ in range(warmup):
+            ev.get_labels_forest(forest5, depth5, lab5)
+        e5 = Events(rt, 2 * steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            e5.record(2 * i)
+            ev.get_labels_forest(forest5, depth5, lab5)
+            e5.record(2 * i + 1)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        kms = float(np.mean([e5.elapsed_ms(2 * i, 2 * i + 1) for i in range(steps)]))
+        e5.destroy()
+        res = {"value": round(F5 * H5 * W5 / wall / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(wall * 1e3, 4),
+               "kernel_ms": round(kms, 4), "steps": steps, "warmup": warmup,
+               "workload": f"{F5} dense {W5}x{H5} frames, T{T5}/D{D5}/C{C5} full forest (config 5's per-GPU shard), 1 GPU"}
+        if check:
+            from oracle import rdf_oracle
+            got = lab5[0:2].get()
+            want = np.full((2, H5, W5), 65535, np.uint16)
+            st = np.zeros(3, np.uint64)
+            rdf_oracle.eval_forest(np.asarray(fr_np[0:2]), np.asarray(f_np), want, n_threads=min(host_cores(), rdf_oracle.max_threads()), stats=st)
+            mism = int((want != got).sum())
+            res["parity"] = {"frames_checked": 2, "pixels": int(want.size), "differing_pixels": mism,
+                             "checker": "oracle/rdf_oracle.c on the host"}
+            assert mism == 0, f"config 5: GPU labels differ from the oracle in {mism} pixels"
+            # algorithmic bytes of the launch: every frame is dense and the topology full, so every pixel
+            # visits T*D records and T leaves -- the two checked frames' counters confirm it
+            assert int(st[0]) == 2 * H5 * W5 and int(st[1]) == 2 * H5 * W5 * T5 * D5 and int(st[2]) == 2 * H5 * W5 * T5
+            res["algorithmic_bytes"] = synth.algorithmic_bytes(F5, H5, W5, 1, False, C5,
+                                                               [F5 * H5 * W5, F5 * H5 * W5 * T5 * D5, F5 * H5 * W5 * T5])
+        del forest5, depth5, lab5
+        torch.cuda.empty_cache()
+        return res
+
+    if a.leg == "cfg5":
+        print(json.dumps({"leg": "cfg5", **leg_cfg5(a.steps, a.warmup, False)}), flush=True)
+        return
+
+    # ================================================================================================================
+    # headline workload
+    # ================================================================================================================
     H, W, F, T, D, C = a.height, a.width, a.frames, a.trees, a.depth, a.classes
-    forest_np = synth.forest(T, D, C, a.topology)
+    forest_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_{a.topology}", lambda: synth.forest(T, D, C, a.topology)))
     forest = rdf.DecisionForest.from_numpy(forest_np)
-    frames_np = synth.mixed_batch(F, first_idx=rank * F, h=H, w=W)
+    frames_np = np.asarray(cached(f"frames_mixed_{F}_{H}x{W}_at{rank * F}", lambda: synth.mixed_batch(F, first_idx=rank * F, h=H, w=W)))
     depth = rdf.to_device(frames_np)
     labels = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
-    ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
-    lib.rdf_set_scheduler({"dynamic": 1, "static": 0, "tile": 2}[a.scheduler])
     if not a.unpacked:
         forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
+
+    # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
+    def leg_cfg2(n1):
+        one_d, one_l = depth[0:1], rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
+        for _ in range(10):
+            ev.get_labels_forest(forest, one_d, one_l)
+        e1 = Events(rt, 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e1.record(0)
+        for _ in range(n1):
+            ev.get_labels_forest(forest, one_d, one_l)
+        e1.record(1)
+        torch.cuda.synchronize()
+        wall1 = (time.perf_counter() - t1) / n1
+        dev1 = e1.elapsed_ms(0, 1) / n1 / 1e3
+        e1.destroy()
+        return {"value": round(H * W / wall1 / 1e6, 2), "unit": "Mpix/s", "ms_per_frame_wall": round(wall1 * 1e3, 4),
+                "ms_per_frame_device": round(dev1 * 1e3, 4), "kernel_ms": round(dev1 * 1e3, 4), "frame": "dense #0",
+                "launches": n1}
+
+    if a.leg == "cfg2":
+        print(json.dumps({"leg": "cfg2", **leg_cfg2(50)}), flush=True)
+        return
+
     # N>1: one launch per step; the gather of step s overlaps the evaluation of step s+1 (two label buffers);
     # --chunks C > 0 selects the in-step pipeline instead (C launches, gather of chunk c overlaps chunk c+1)
     chunks = a.chunks or 1
@@ -161,25 +321,13 @@ def main():
 
     # N>1, default: peer copies over xGMI by the copy engines (RCCL carries only the control plane); needs HIP IPC
     # between the ranks' processes, falls back to the RCCL gather if any rank cannot map rank 0's buffer
-    peer = None
-    if world > 1 and a.chunks == 0 and a.gather in ("auto", "p2p"):
+    peer, pg = None, None
+    if world > 1 and a.chunks == 0 and a.gather in ("auto", "p2p", "both"):
         pg = dmod.PeerCopyGather(world, rank, F * H * W * 2)
         if pg.ok:
             peer = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg)
         elif a.gather == "p2p":
             sys.exit("--gather p2p: rank 0's receive buffer could not be mapped by every rank")
-    gather_mode = None if world == 1 else ("p2p copy engines" if peer is not None else "rccl gather")
-
-    def one_step():
-        if peer is not None:
-            peer.step(depth, ring)
-        elif overlapped:
-            sharded.step_overlapped(depth, ring)
-        else:
-            sharded.step(depth, labels)
-
-    def drain():
-        (peer if peer is not None else sharded).drain()
 
     # ---- algorithmic bytes of one step, from the visit counters of the same walk ----
     dstats = rdf.DeviceArray((3,), np.uint64).fill(0)
@@ -190,75 +338,108 @@ def main():
     stats = dstats.get()
     alg_bytes = synth.algorithmic_bytes(F, H, W, 1, False, C, stats)
 
-    # ---- N>1: the compute stream leaves one CU per shader engine to RCCL (its send/recv kernel cannot start beside the
+    # ---- a compute stream that leaves one CU per shader engine to RCCL (its send/recv kernel cannot start beside the
     # forest kernel's persistent workgroups otherwise: tools/ubench_overlap.py) ----
-    reserve = a.reserve_cus if a.reserve_cus >= 0 else (32 if world > 1 and peer is None else 0)
-    compute_stream, masked_handle = None, None
-    if reserve > 0:
+    def masked_stream(reserve):
         import ctypes
         h = ctypes.c_void_p()
         rc_m = lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), reserve)
-        if rc_m == 0:
-            masked_handle = h
-            compute_stream = torch.cuda.ExternalStream(h.value)
-        else:
+        if rc_m != 0:
             print(f"rank {rank}: no CU-masked stream ({lib.rdf_error_string(rc_m)}); using the current stream", file=sys.stderr)
-            reserve = 0
-    torch.cuda.synchronize()
-    import contextlib
-    stream_ctx = torch.cuda.stream(compute_stream) if compute_stream is not None else contextlib.nullcontext()
+            return None, None
+        return h, torch.cuda.ExternalStream(h.value)
 
-    # ---- timed region ----
-    def sync_all():
-        torch.cuda.synchronize()
+    def timed(step_fn, drain_fn, stream):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            for _ in range(a.warmup):
+                step_fn()
+            drain_fn()
+            evs = Events(rt, 2 * a.steps)
+            sync_all()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                evs.record(2 * i)
+                step_fn()
+                evs.record(2 * i + 1)
+            drain_fn()              # every step's label maps are on rank 0 before the clock stops
+            sync_all()
+            elapsed = time.perf_counter() - t0
+            kms = [evs.elapsed_ms(2 * i, 2 * i + 1) for i in range(a.steps)]
+            evs.destroy()
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, kms
 
-    with stream_ctx:
-        for _ in range(a.warmup):
-            one_step()
-        drain()
-        evs = Events(rt, 2 * a.steps)
-        sync_all()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            evs.record(2 * i)
-            one_step()
-            evs.record(2 * i + 1)
-        drain()              # every step's label maps are on rank 0 before the clock stops
-        sync_all()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = [evs.elapsed_ms(2 * i, 2 * i + 1) for i in range(a.steps)]
-    evs.destroy()
-    assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"
-
-    # ---- N>1: did rank 0 really receive every rank's label maps?  (checksum of checksums) ----
-    gather_check = None
-    if world > 1:
+    def gather_check(result_fn, from_peer):
+        """Did rank 0 really receive every rank's label maps?  (checksum of checksums)"""
         mine = labels.torch_bytes().view(torch.int16).to(torch.int64)
         sums = torch.stack([mine.sum(), (mine * (torch.arange(mine.numel(), device=mine.device) % 8191)).sum()])
         allsums = [torch.zeros_like(sums) for _ in range(world)]
         dist.all_gather(allsums, sums)
-        if rank == 0:
-            got = peer.result() if peer is not None else sharded.result()
-            ok = True
-            for g in range(world):
-                part = got[g * F:(g + 1) * F]
-                part = (part.reshape(-1) if peer is not None else part.torch_bytes().view(torch.int16)).to(torch.int64)
-                chk = torch.stack([part.sum(), (part * (torch.arange(part.numel(), device=part.device) % 8191)).sum()])
-                ok = ok and bool(torch.equal(chk, allsums[g]))
-            gather_check = "ok" if ok else "MISMATCH"
+        if rank != 0:
+            return None
+        got = result_fn()
+        ok = True
+        for g in range(world):
+            part = got[g * F:(g + 1) * F]
+            part = (part.reshape(-1) if from_peer else part.torch_bytes().view(torch.int16)).to(torch.int64)
+            chk = torch.stack([part.sum(), (part * (torch.arange(part.numel(), device=part.device) % 8191)).sum()])
+            ok = ok and bool(torch.equal(chk, allsums[g]))
+        return "ok" if ok else "MISMATCH"
+
+    modes = {}          # name -> (step, drain, stream, reserve, result_fn, from_peer)
+    handles = []
+    if world == 1:
+        modes["none"] = (lambda: sharded.step(depth, labels), sharded.drain, None, 0, None, False)
+    else:
+        if peer is not None:
+            modes["p2p copy engines"] = (lambda: peer.step(depth, ring), peer.drain, None, 0, peer.result, True)
+        if peer is None or a.gather in ("rccl", "both"):
+            reserve = a.reserve_cus if a.reserve_cus >= 0 else 32
+            h, st = masked_stream(reserve) if reserve > 0 else (None, None)
+            handles.append(h)
+            step = (lambda: sharded.step_overlapped(depth, ring)) if overlapped else (lambda: sharded.step(depth, labels))
+            modes["rccl gather"] = (step, sharded.drain, st, reserve if st is not None else 0, sharded.result, False)
+        if a.gather == "rccl" and "p2p copy engines" in modes:
+            del modes["p2p copy engines"]
+    torch.cuda.synchronize()
+
+    results = {}
+    for name, (step, drain, st, reserve, result_fn, from_peer) in modes.items():
+        elapsed, kms = timed(step, drain, st)
+        results[name] = {"elapsed": elapsed, "kern_ms": kms, "reserve": reserve,
+                         "gather_check": gather_check(result_fn, from_peer) if world > 1 else None}
+    primary = next(iter(results))
+    elapsed, kern_ms = results[primary]["elapsed"], results[primary]["kern_ms"]
+    assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"
+
+    # ---- the kernel alone on every rank (no gather enqueued): Mpix/s with and without the gather, SURVEY 8(e) ----
+    kern_only = None
+    if world > 1:
+        ek = Events(rt, 2)
+        sync_all()
+        ek.record(0)
+        for _ in range(a.steps):
+            ev.get_labels_forest(forest, depth, labels)
+        ek.record(1)
+        t = torch.tensor([ek.elapsed_ms(0, 1) / a.steps], dtype=torch.float64, device="cuda")
+        ek.destroy()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kern_only = float(t.item())
 
     pix_per_step = world * F * H * W
     value = pix_per_step * a.steps / elapsed / 1e6
-    kern_avg_s = float(np.mean(kern_ms)) / 1e3
-    achieved = alg_bytes / kern_avg_s / 1e9
+    kern_avg_ms = float(np.mean(kern_ms))
 
+    if a.leg == "headline":
+        print(json.dumps({"leg": "headline", "kernel_ms": round(kern_avg_ms, 4), "value": round(value, 2)}), flush=True)
+        return
+
+    gather_mode = None if world == 1 else primary
     out = {
         "metric": "classified Mpix/s on 848x480 depth frames (4 trees, depth 20); % HBM roofline",
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -269,20 +450,33 @@ def main():
                                + (f"labels gathered to rank 0 ({gather_mode}; control plane {a.backend}) inside the timed region" if world > 1 else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
                    "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
-                   "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": reserve, "gather": gather_mode, "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if world > 1 else None)), "sharding": f"frames x{world}, forest replicated",
-                   "gather_check": gather_check},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": load_traffic(f"F{F}_T{T}_D{D}_C{C}_{a.topology}"),
-                     "kernel": "k_eval_forest", "kernel_ms": round(kern_avg_s * 1e3, 4),
-                     "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "algorithmic_bytes_per_pixel": round(alg_bytes / (F * H * W), 1),
-                     "visits": {"pixels": int(stats[0]), "node_records": int(stats[1]), "leaves": int(stats[2])}},
+                   "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": results[primary]["reserve"],
+                   "gather": gather_mode,
+                   "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if world > 1 else None)),
+                   "sharding": f"frames x{world}, forest replicated", "gather_check": results[primary]["gather_check"]},
     }
+    if world > 1:
+        # what a driver needs to verify the run: N ranks of ONE RCCL communicator on N distinct devices
+        uuid = str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", f"index-{dev_index}"))
+        ids = [None] * world
+        dist.all_gather_object(ids, {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "uuid": uuid,
+                                     "name": torch.cuda.get_device_name(dev_index)})
+        out["distributed"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": ids,
+                              "distinct_devices": len({d["uuid"] for d in ids}),
+                              "kernel_only_ms": round(kern_only, 4),
+                              "value_kernel_only": round(pix_per_step / (kern_only * 1e-3) / 1e6, 2),
+                              "gather_modes": {n: {"ms_per_step": round(r["elapsed"] / a.steps * 1e3, 4),
+                                                   "value": round(pix_per_step * a.steps / r["elapsed"] / 1e6, 2),
+                                                   "cus_left_to_rccl": r["reserve"], "gather_check": r["gather_check"]}
+                                               for n, r in results.items()}}
 
-    if rank == 0 and world == 1 and not a.headline_only:
-        # ---- what HBM really delivers to a plain stream: a 1-GB device-to-device copy (SURVEY 8d asks for the roofline
-        # against the spec peak AND a measured copy ceiling) ----
+    key = f"F{F}_T{T}_D{D}_C{C}_{a.topology}"
+    out["roofline"] = roofline_for("headline", key, live, kern_avg_ms, alg_bytes)
+    out["roofline"]["algorithmic"].update({"bytes_per_pixel": round(alg_bytes / (F * H * W), 1),
+                                           "visits": {"pixels": int(stats[0]), "node_records": int(stats[1]), "leaves": int(stats[2])}})
+
+    if rank == 0 and full_run:
+        # ---- what HBM really delivers to a plain stream: a 1-GB device-to-device copy ----
         src_t = torch.empty(1 << 30, dtype=torch.uint8, device="cuda").fill_(1)
         dst_t = torch.empty_like(src_t)
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -296,31 +490,17 @@ def main():
             best = ms if best is None else min(best, ms)
         ceiling = 2.0 * (1 << 30) / (best * 1e-3) / 1e9      # bytes read + bytes written
         out["roofline"]["copy_ceiling"] = {"value": round(ceiling, 1), "unit": "GB/s",
-                                           "frac_of_ceiling": round(achieved / ceiling, 4),
-                                           "hbm_traffic_gbs": (round(out["roofline"]["traffic"] / kern_avg_s / 1e9, 1)
-                                                               if out["roofline"]["traffic"] else None),
                                            "what": "1-GB device-to-device copy, read + written bytes per second"}
         del src_t, dst_t
 
-        # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
-        one_d, one_l = depth[0:1], rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
-        for _ in range(10):
-            ev.get_labels_forest(forest, one_d, one_l)
-        n1 = 200
-        e1 = Events(rt, 2)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        e1.record(0)
-        for _ in range(n1):
-            ev.get_labels_forest(forest, one_d, one_l)
-        e1.record(1)
-        torch.cuda.synchronize()
-        wall1 = (time.perf_counter() - t1) / n1
-        dev1 = e1.elapsed_ms(0, 1) / n1 / 1e3
-        e1.destroy()
-        out["cfg2_single_frame"] = {"value": round(H * W / wall1 / 1e6, 2), "unit": "Mpix/s",
-                                    "ms_per_frame_wall": round(wall1 * 1e3, 4), "ms_per_frame_device": round(dev1 * 1e3, 4),
-                                    "frame": "dense #0", "launches": n1}
+        c2 = leg_cfg2(200)
+        one_stats = rdf.DeviceArray((3,), np.uint64).fill(0)
+        one_l = rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
+        assert lib.rdf_eval_forest_stats(depth.ptr, 1, W, H, forest.forest_cu.ptr, T, D, C, None, -1, one_l.ptr, 1, 1.0,
+                                         one_stats.ptr, rt.stream()) == 0
+        c2["roofline"] = roofline_for("cfg2", f"F1_T{T}_D{D}_C{C}_{a.topology}", live, c2["kernel_ms"],
+                                      synth.algorithmic_bytes(1, H, W, 1, False, C, one_stats.get()))
+        out["cfg2_single_frame"] = c2
 
         # ---- config 3: 2-layer stack through LayeredDecisionForest.run (run_live_layered.py:126), r = 2 ----
         cfg3 = {"layers": [{"model": forest}, {"model": forest, "filter_model": 0, "filter_model_class": 3}],
@@ -339,11 +519,10 @@ def main():
         w3 = (time.perf_counter() - t3) / 100
         out["cfg3_layered_run"] = {"ms_per_frame_wall": round(w3 * 1e3, 4), "value": round(H * W / w3 / 1e6, 2),
                                    "unit": "Mpix/s", "what": "LayeredDecisionForest.run, 2 layers (second filtered on "
-                                   "class 3 of the first), labels_reduce 2, one live-like 848x480 frame: 3 fills + 2 "
-                                   "forest launches + composite"}
+                                   "class 3 of the first), labels_reduce 2, one live-like 848x480 frame: ONE C-ABI call, 2 "
+                                   "forest launches + composite (the reference's three fills are folded into them)"}
 
         # ---- host-buffer variant: pinned H2D of the frames + kernel + D2H of the labels (never `value`) ----
-        # Opt-in: its launches carry the headline kernel's name and would blur rocprofv3's per-kernel average.
         if a.pcie:
             pin_in = torch.from_numpy(frames_np.view(np.int16).reshape(-1)).pin_memory()
             pin_out = torch.empty(F * H * W, dtype=torch.int16).pin_memory()
@@ -407,9 +586,8 @@ def main():
             from oracle import rdf_oracle  # the checker; never the thing measured as `value`
             got = labels.get()
             cores = min(host_cores(), rdf_oracle.max_threads())
-            order = list(range(F))  # the batch alternates dense / live-like frames
             done, t_cpu, mism = 0, 0.0, 0
-            for i in order:
+            for i in range(F):      # the batch alternates dense / live-like frames
                 want = np.full((1, H, W), 65535, np.uint16)
                 tc = time.perf_counter()
                 rdf_oracle.eval_forest(frames_np[i:i + 1], forest_np, want, n_threads=cores)
@@ -434,16 +612,30 @@ def main():
                                          "kind": "port", "sample": f"1 live-like frame, {tn:.1f} s of oracle/rdf_numpy.py; "
                                          f"labels differ from the GPU's in {int((wn[0] != got[1]).sum())} pixels"}
 
+        # ---- config 5's shard last: it frees the headline's buffers first (2 GiB forest + 2.5 GiB packed tables) ----
+        if not a.no_cfg5:
+            del forest, depth, labels, scratch, sharded, lf
+            torch.cuda.empty_cache()
+            c5 = leg_cfg5(5, 2, True)
+            c5["roofline"] = roofline_for("cfg5", f"F{a.cfg5_frames}_T8_D22_C4_full_1280x720", live, c5["kernel_ms"],
+                                          c5.pop("algorithmic_bytes", None))
+            out["cfg5_shard"] = c5
+        if live:
+            out["counter_passes"] = {leg: {"seconds": v["seconds"], "log": v["log"]} for leg, v in live.items()}
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        if peer is not None:            # unmap on the peers before rank 0 frees the buffer
+        if pg is not None and pg.ok:            # unmap on the peers before rank 0 frees the buffer
             if rank != 0:
                 pg.close()
             dist.barrier()
             if rank == 0:
                 pg.close()
+        for h in handles:
+            if h is not None:
+                lib.rdf_stream_destroy(h)
         dist.destroy_process_group()
 
 

@@ -91,6 +91,23 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers,
                     int labels_reduce, float scale_factor, void *stream);
 
 /*
+ * rdf_layered_run plus what the app does with the composite of one hand (src/3d_bz.py:440-456), folded into the composite
+ * kernel's store instead of three more launches: flip_x != 0 writes the composite mirrored in x (the left hand's frame
+ * was flipped on the way in, :402-404, and its labels are flipped back, :441-447) and image_rgba, if not NULL, receives
+ * colors_rgba[label - 1] for every pixel that gets a label in 1..num_colors, at the place the label is written
+ * (make_rgba_from_labels, src/cuda/points_ops.cu:258-281; other texels are left alone).  The per-layer label images
+ * stay unflipped.
+ */
+int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_layers,
+                         const void *const *packed, const float *const *forests,
+                         const int *n_trees, const int *max_depth, const int *n_classes,
+                         const int *filter_layer, const int *filter_class,
+                         uint16_t *const *layer_labels, const uint16_t *const *layer_labels_dev_table,
+                         const int32_t *cond, int n_cond, uint16_t *composite_out, int32_t *bad_count,
+                         int labels_reduce, float scale_factor, int flip_x, const uint8_t *colors_rgba,
+                         int num_colors, uint8_t *image_rgba, void *stream);
+
+/*
  * Load-time repack of a forest into a table of 16-byte hot records {23-bit floor(s*u), 23-bit
  * floor(s*v), integer threshold, leaf flags} followed by a table of 32-byte exact records
  * (fp32 s*u, s*v) that is read only for nodes whose numerators the integer form cannot
@@ -98,10 +115,7 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers,
  * [right: ...] per node.  The reference has no counterpart: its "load" is the plain upload at
  * src/decision_tree.py:148-158.  The packed tables depend on scale_factor and must be rebuilt
  * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes
- * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree, plus the subtree-blocked copy of the
- * hot records of the levels below the top k0 = 4..6: 128 * 2^k0 * (8^((max_depth - k0) / 3) - 1) / 7 bytes per tree, in
- * which a node, its children and grandchildren share one 128-byte line).  Packed tables support max_depth <= 27 (32-bit
- * byte offsets inside one tree).
+ * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
@@ -170,6 +184,12 @@ int rdf_setup_depth_image_for_forest(const float *pts_xyzw, uint16_t *depth, siz
 int rdf_stencil_depth_image_by_group(int dim_x, int dim_y, int mipmap_level, int group, const uint16_t *groups_in,
                                      const uint16_t *depth_in, uint16_t *depth_out, void *stream);
 int rdf_flip_x(int dim_x, int dim_y, const uint16_t *in, uint16_t *out, void *stream);
+/* The app's per-hand input chain (src/3d_bz.py:396-420) in one pass: depth_out[y][x'] = depth_in[y][x] where the pixel's
+ * hand group (groups_in at mip level mipmap_level, as rdf_stencil_depth_image_by_group reads it) equals `group` and the
+ * depth is not 0, else 65535; x' = dim_x - 1 - x if flip_x.  Equals fill(0) + rdf_stencil_depth_image_by_group +
+ * rdf_flip_x (or a copy) + rdf_convert_0s_to_maxuint.  depth_in and depth_out may be the same buffer only when flip_x == 0. */
+int rdf_prepare_hand_depth(int dim_x, int dim_y, int mipmap_level, int group, const uint16_t *groups_in,
+                           const uint16_t *depth_in, uint16_t *depth_out, int flip_x, void *stream);
 int rdf_make_rgba_from_labels(int dim_x, int dim_y, int num_colors, const uint16_t *labels,
                               const uint8_t *colors_rgba, uint8_t *image_rgba, void *stream);
 
@@ -260,7 +280,6 @@ void rdf_set_rows_per_wave(int rows);    /* label rows per wave in a tile: 1, 2 
 void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (24) */
 void rdf_set_lds_levels(int levels);     /* top levels of every tree pinned in LDS (the depth tile then gets the rest of
                                             the LDS budget instead of half of it); -1 = fill what the tile leaves */
-void rdf_set_blocked(int on);            /* deep levels read from the subtree-blocked copy of the packed table: 1/-1 (default) on, 0 off */
 void rdf_set_stage_vec(int on);          /* tile staging with 16-byte loads where alignment allows: 1/-1 (default) on, 0 off */
 void rdf_set_force_exact(int on);        /* test knob: rdf_forest_pack flags every node for the IEEE-divide path */
 

@@ -84,7 +84,22 @@ def main():
         both()
     torch.cuda.synchronize()
     d2 = (time.perf_counter() - t0) / n
+    # the reference's sequence of separate kernels around the forest (fused_io=False), as a graph, for comparison
+    pipe_ref = pl.HandPipeline(lf, (H, W), R, 1.0, 6, np.full(7, 40., np.float32), [3, 4, 5, 6, 7],
+                               (421.3, 420.9, 423.1, 238.6), np.eye(4, dtype=np.float32), fused_io=False)
+    r_ref = pipe_ref.capture(dbuf, gbuf, 1, False)
+    a, b = r_ref(), replays[0]()
+    assert np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64)) and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64))
+    for _ in range(20):
+        r_ref()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        r_ref()
+    torch.cuda.synchronize()
+    dref = (time.perf_counter() - t0) / n
     print(json.dumps({"hand_pipeline": {"frame": [H, W], "labels_reduce": R, "layers": 2, "trees": 4, "tree_depth": 18,
+                                        "us_per_hand_per_frame_as_hipgraph_unfused_io": round(dref * 1e6, 1),
                                         "mean_shift_rounds": 6, "us_per_hand_per_frame": round(dt * 1e6, 1),
                                         "us_per_hand_per_frame_as_hipgraph": round(dg * 1e6, 1),
                                         "hands_per_second_as_hipgraph": round(1 / dg, 1),

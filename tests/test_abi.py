@@ -37,9 +37,8 @@ def test_binding_table_matches_header(rdf):
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
     assert lib.rdf_abi_version() == _lib.ABI_VERSION
-    assert lib.rdf_forest_packed_bytes(4, 20, 4) == (4 << 20) * (48 + 32) + 4 * 128 * 32 * 4681      # + blocked copy, k0 = 5
-    assert lib.rdf_forest_packed_bytes(3, 10, 5) == (3 << 10) * (48 + 64) + 3 * 128 * 16 * 9          # k0 = 4
-    assert lib.rdf_forest_packed_bytes(2, 6, 4) == (2 << 6) * (48 + 32)                                # too shallow to block
+    assert lib.rdf_forest_packed_bytes(4, 20, 4) == (4 << 20) * (48 + 32)
+    assert lib.rdf_forest_packed_bytes(3, 10, 5) == (3 << 10) * (48 + 64)
     assert b"2^31" in lib.rdf_error_string(-3)
 
 

@@ -82,9 +82,10 @@ def test_shard_range_partitions_the_batch(rdf):
     assert dmod.shard_range(1024, 3, 8) == (384, 512)
 
 
-def _p2p_worker(rank, world, port, tmpdir):
+def _p2p_worker(rank, world, port, tmpdir, multi_device=False):
     """Two processes on the one GPU of the test box: rank 0 exports its receive buffer, rank 1 maps it through HIP
-    IPC, both copy their label maps in with hipMemcpyAsync on a side stream; gloo only carries the control plane."""
+    IPC, both copy their label maps in with hipMemcpyAsync on a side stream; gloo only carries the control plane.
+    multi_device: rank g uses GPU g (the copy then crosses xGMI) and RCCL carries the control plane."""
     import torch
     import torch.distributed as dist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -92,13 +93,16 @@ def _p2p_worker(rank, world, port, tmpdir):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank if multi_device else 0)
     rdf = importlib.import_module("3d-beats_amd")
     dmod = importlib.import_module("3d-beats_amd.distributed")
     from oracle import rdf_oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if multi_device:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         frames, h, w, r = 6, 120, 200, 2
         forest_np = rdf.synth.forest(4, 9, 4, "trained")
@@ -140,6 +144,18 @@ def _p2p_worker(rank, world, port, tmpdir):
 def test_two_process_peer_copy_gather_on_one_gpu(tmp_path, oracle):
     import torch.multiprocessing as mp
     mp.spawn(_p2p_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+@pytest.mark.gpu
+def test_peer_copy_gather_across_two_devices(tmp_path, oracle):
+    """The same exchange with the two ranks on two DIFFERENT GPUs: rank 1's hipMemcpyAsync into rank 0's IPC-mapped
+    buffer crosses xGMI, RCCL carries the control plane.  Needs a box with at least two GPUs (the 1-GPU test box skips)."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    mp.spawn(_p2p_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
 
 

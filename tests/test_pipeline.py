@@ -34,8 +34,9 @@ def _config(rdf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused_io", [True, False])
 @pytest.mark.parametrize("flip_x", [False, True])
-def test_hand_pipeline_matches_the_chain_of_restatements(flip_x, rdf, gpu_runtime, oracle):
+def test_hand_pipeline_matches_the_chain_of_restatements(flip_x, fused_io, rdf, gpu_runtime, oracle):
     pl = importlib.import_module("3d-beats_amd.pipeline")
     depth, groups = _scene(rdf)
     f0, f1, conditions, colors = _config(rdf)
@@ -50,7 +51,9 @@ def test_hand_pipeline_matches_the_chain_of_restatements(flip_x, rdf, gpu_runtim
     intr = (421.3, 420.9, 423.1, 238.6)
     tips = [3, 4, 5, 6, 7]
     ratio = 0.75
-    pipe = pl.HandPipeline(lf, (H, W), R, ratio, 5, variances, tips, intr, plane)
+    # fused_io: stencil + flip + 0->65535 as one kernel, flip back + colouring on the composite's store; otherwise the
+    # reference's sequence of separate kernels -- same bytes either way
+    pipe = pl.HandPipeline(lf, (H, W), R, ratio, 5, variances, tips, intr, plane, fused_io=fused_io)
     dbuf, gbuf = rdf.GpuBuffer((H, W), np.uint16), rdf.GpuBuffer((H, W), np.uint16)
     dbuf.cu().set(depth)
     gbuf.cu().set(groups)

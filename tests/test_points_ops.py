@@ -74,3 +74,37 @@ def test_pointsops_byte_exact_on_gpu(rdf, gpu_runtime):
         img = rdf.to_device(np.full((h, w, 4), 3, np.uint8))
         ops.make_rgba_from_labels(np.uint32(w), np.uint32(h), np.uint32(6), rdf.to_device(labels), rdf.to_device(cols), img)
         assert np.array_equal(img.get(), po_np.make_rgba_from_labels(labels, cols, np.full((h, w, 4), 3, np.uint8)))
+
+
+@pytest.mark.gpu
+def test_prepare_hand_depth_equals_the_chain_it_replaces(rdf, gpu_runtime):
+    """rdf_prepare_hand_depth == fill(0) -> stencil_depth_image_by_group -> flip_x (or copy) -> convert_0s_to_maxuint
+    (3d_bz.py:396-420), byte for byte: vector and scalar widths, every mip level, both orientations, in place."""
+    pmod = importlib.import_module("3d-beats_amd.cuda.points_ops")
+    ops = pmod.PointsOps()
+    rng = np.random.default_rng(33)
+    for (h, w) in [(480, 848), (37, 53), (1, 1), (240, 424), (16, 8), (9, 24)]:
+        depth = rdf.synth.live_frame(9, h, w) if h > 8 else rng.integers(0, 3, size=(h, w)).astype(np.uint16)
+        depth[rng.random((h, w)) < 0.1] = 0
+        for level in (0, 1, 3):
+            f = 1 << level
+            gw, gh = max(w // f, 1), max(h // f, 1)
+            groups = rng.integers(0, 3, size=(gh, gw)).astype(np.uint16)
+            g_host = groups if w // f and h // f else groups[:0]
+            for group in (1, 2):
+                for flip in (False, True):
+                    want = po_np.stencil_depth_image_by_group(w, h, level, group, g_host, depth, np.zeros((h, w), np.uint16))
+                    want = want[:, ::-1].copy() if flip else want
+                    po_np.convert_0s_to_maxuint(want)
+                    out = rdf.to_device(np.full((h, w), 7, np.uint16))
+                    ops.prepare_hand_depth(np.array([w, h], np.int32), level, group, rdf.to_device(groups), rdf.to_device(depth),
+                                           out, flip)
+                    assert np.array_equal(out.get(), want), (h, w, level, group, flip)
+            inplace = rdf.to_device(depth)
+            ops.prepare_hand_depth(np.array([w, h], np.int32), level, 1, rdf.to_device(groups), inplace, inplace, False)
+            want = po_np.convert_0s_to_maxuint(po_np.stencil_depth_image_by_group(w, h, level, 1, g_host, depth,
+                                                                                  np.zeros((h, w), np.uint16)))
+            assert np.array_equal(inplace.get(), want)
+    d = rdf.to_device(np.ones((4, 8), np.uint16))
+    rc = gpu_runtime.lib.rdf_prepare_hand_depth(8, 4, 0, 1, d.ptr, d.ptr, d.ptr, 1, gpu_runtime.stream())
+    assert rc == -1      # a flip in place is refused

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Hierarchical roofline of the forest kernel: HBM, L2->L1 line fills, the L1/texture-addresser pipeline and VALU issue.
+
+SURVEY 8(d) prices the kernel against HBM with ALGORITHMIC bytes (32 B per node visit).  Most of those bytes are served
+by LDS, L1 and L2, so that figure exceeds the HBM peak (round 1: 1.84x) and bounds nothing.  This module turns the
+rocprofv3 counters of one launch into the time each level of the memory/issue hierarchy needs for that launch at its own
+measured peak; the level that needs the largest share of the kernel's duration is the bound, and that share is
+`roofline.frac` (in (0, 1] by construction, up to the accuracy of the calibration).
+
+Calibration constants (profiles/r02_ubench_*.txt, tools/ubench_valu.hip, tools/ubench_fetch.hip, tools/ubench_vmem.hip;
+MI355X_MICROARCH.md for the peaks):
+  * FETCH_SIZE = TCC_EA0_RDREQ x 64 B although every request of this kernel's patterns (2-byte probes, 16-byte records,
+    coalesced staging) moves a whole 128-byte line: HBM-side read bytes = TCC_EA0_RDREQ x 128 (= 2 x FETCH_SIZE);
+    WRITE_SIZE is exact.  Infinity-Cache hits are included, so this is an upper bound of what HBM itself delivers.
+  * TCP_TCC_READ_REQ counts 128-byte line requests (one per line for every access width): L2->L1 bytes = requests x 128,
+    peak 64 B/clk/CU.
+  * L1/TA pipeline: a divergent wave-level load holds the CU's address/tag pipeline 0.6 cycles per line served by L1 and
+    2.35 cycles per line that has to be filled from L2 (tools/ubench_vmem.hip).
+  * VALU issue with more than one wave per SIMD: 2.35 cycles for the simple integer/fp32 instructions, 4.2 cycles for
+    v_pk_*_f32, conversions, v_perm_b32 and the three-operand integer forms (tools/ubench_valu.hip); the kernel's mix is
+    counted in its ISA (VALU_MIX below).
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HBM_PEAK_GBS = 8000.0          # spec, MI355X_MICROARCH.md
+L2_L1_BYTES_PER_CLK_PER_CU = 64.0
+LINE = 128
+CUS = 256
+SIMDS = 4 * CUS
+TA_CYCLES_PER_L1_HIT = 0.6     # profiles/r01_ubench_vmem.txt: 38.6 cycles per 64-line instruction served by L1
+TA_CYCLES_PER_L2_FILL = 2.35   # ... 151 cycles per 64-line instruction served by L2
+VALU_FULL_RATE_CYCLES = 2.35   # profiles/r02_ubench_valu.txt
+VALU_HALF_RATE_CYCLES = 4.2
+# share of the walk loop's VALU instructions that issue at the half rate (v_pk_*, v_cvt_*, v_perm, v_mad_u32_u24,
+# v_lshl_add_u32, v_add_lshl_u32, v_or3, v_bfe, v_mul_u32_u24 ...), counted in the ISA of k_eval_forest<256,true,4,...>
+VALU_HALF_RATE_SHARE = 0.80
+
+PASSES = [
+    ("fetch", "FETCH_SIZE"),
+    ("write", "WRITE_SIZE TCC_EA0_RDREQ_sum"),
+    ("tcc", "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"),
+    ("tcp", "TCP_TCC_READ_REQ_sum"),
+    ("tcpacc", "TCP_TOTAL_CACHE_ACCESSES_sum"),
+    ("sq", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"),
+    ("grbm", "GRBM_GUI_ACTIVE"),
+    ("ta", "TA_TA_BUSY_sum"),
+]
+
+
+def parse_counters(root, kernel_substr):
+    """Mean of every counter over the dispatches of the most frequently launched kernel whose name contains
+    `kernel_substr` (rocprofv3 --pmc --output-format csv trees under `root`)."""
+    acc = {}
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = row.get("Kernel_Name", "")
+                if kernel_substr not in k:
+                    continue
+                d = acc.setdefault(k, {})
+                d.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                try:    # the dispatch's own duration in this (profiled) pass, for the clock estimate
+                    d.setdefault("_ns:" + row["Counter_Name"], []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                    d.setdefault("_vgpr", []).append(float(row["VGPR_Count"]))
+                    d.setdefault("_lds_bytes", []).append(float(row["LDS_Block_Size"]))
+                    d.setdefault("_grid", []).append(float(row["Grid_Size"]))
+                except (KeyError, ValueError):
+                    pass
+    if not acc:
+        return None, {}
+    name = max(acc, key=lambda k: max(len(v) for v in acc[k].values()))
+    return name, {c: sum(v) / len(v) for c, v in acc[name].items()}
+
+
+def collect(cmd, kernel_substr, timeout=240, passes=PASSES, keep_dir=None):
+    """Runs `cmd` (a list, the program itself first: rocprofv3 must not be handed a launcher) once per counter set under
+    rocprofv3 --pmc and returns (kernel name, {counter: mean per launch}, log lines).  Each pass is its own process; a
+    pass that fails or times out is skipped.  Call this BEFORE the calling process touches the GPU."""
+    if shutil.which("rocprofv3") is None:
+        return None, {}, ["rocprofv3 not found"]
+    out, log, name = {}, [], None
+    base = keep_dir or tempfile.mkdtemp(prefix="rdf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for tag, ctrs in passes:
+        d = os.path.join(base, tag)
+        full = ["rocprofv3", "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "--"] + list(cmd)
+        try:
+            r = subprocess.run(full, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            log.append(f"pass {tag}: rc={r.returncode}")
+            if r.returncode != 0:
+                log.append(r.stderr.decode(errors="replace")[-400:])
+                continue
+        except Exception as e:  # timeout, missing tool
+            log.append(f"pass {tag}: {type(e).__name__}: {e}")
+            continue
+        k, vals = parse_counters(d, kernel_substr)
+        if vals:
+            name = name or k
+            out.update(vals)
+    if keep_dir is None:
+        shutil.rmtree(base, ignore_errors=True)
+    return name, out, log
+
+
+def model(counters, kernel_ms, alg_bytes=None, cus=CUS):
+    """The four levels for one launch; returns the `roofline` object of bench.py's JSON line."""
+    t = kernel_ms * 1e-3
+    c = counters or {}
+    levels = {}
+    clk = None
+    if c.get("GRBM_GUI_ACTIVE"):
+        # rocprofv3 sums the 8 XCDs; divided by the dispatch's duration in the SAME (profiled) pass when the CSV has it
+        t_prof = c.get("_ns:GRBM_GUI_ACTIVE", 0.0) * 1e-9
+        clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (t_prof if t_prof > 0 else t)
+    clk_used = clk or 2.3e9
+    cyc = clk_used * t                                 # kernel duration in shader cycles
+
+    # ---- HBM (fabric side of L2; includes Infinity-Cache hits) ----
+    hbm = None
+    rd = c.get("TCC_EA0_RDREQ_sum")
+    if rd is not None:
+        rd_bytes = rd * LINE
+    elif c.get("FETCH_SIZE") is not None:
+        rd_bytes = c["FETCH_SIZE"] * 1024.0 * 2.0      # 128-byte requests tallied at 64 B
+    else:
+        rd_bytes = None
+    if rd_bytes is not None and c.get("WRITE_SIZE") is not None:
+        hbm = rd_bytes + c["WRITE_SIZE"] * 1024.0
+        a = hbm / t / 1e9
+        levels["hbm"] = {"achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                         "bytes_per_launch": int(hbm),
+                         "what": "L2 fabric-side read requests x 128 B + WRITE_SIZE (Infinity-Cache hits included)"}
+    # ---- L2 -> L1 line fills ----
+    fills = c.get("TCP_TCC_READ_REQ_sum")
+    if fills is not None:
+        a = fills * LINE / t / 1e9
+        peak = L2_L1_BYTES_PER_CLK_PER_CU * cus * clk_used / 1e9
+        levels["l2_l1"] = {"achieved": round(a, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(a / peak, 4),
+                           "line_fills_per_launch": int(fills),
+                           "what": "TCP_TCC_READ_REQ x 128 B against 64 B/clk/CU at the measured clock"}
+    # ---- L1 / texture-addresser pipeline ----
+    acc = c.get("TCP_TOTAL_CACHE_ACCESSES_sum")
+    if fills is not None and acc is not None:
+        hits = max(acc - fills, 0.0)
+        ta_cycles = (hits * TA_CYCLES_PER_L1_HIT + fills * TA_CYCLES_PER_L2_FILL) / cus
+        levels["l1_ta"] = {"achieved": round(ta_cycles / 1e6, 3), "peak": round(cyc / 1e6, 3), "unit": "Mcycles per CU",
+                           "frac": round(ta_cycles / cyc, 4), "l1_line_accesses_per_launch": int(acc),
+                           # cross-check from the hardware's own busy counter (cycles the texture addresser is busy,
+                           # summed over the CUs, in the profiled pass that collected it)
+                           "ta_busy_frac_counter": (round(c["TA_TA_BUSY_sum"] / cus / (c["_ns:TA_TA_BUSY_sum"] * 1e-9 * clk_used), 4)
+                                                    if c.get("TA_TA_BUSY_sum") and c.get("_ns:TA_TA_BUSY_sum") else None),
+                           "what": f"(L1 line accesses - fills) x {TA_CYCLES_PER_L1_HIT} + fills x {TA_CYCLES_PER_L2_FILL} "
+                                   "cycles (tools/ubench_vmem.hip) per CU against the kernel's cycles"}
+    # ---- VALU issue ----
+    valu = c.get("SQ_INSTS_VALU")
+    if valu is not None:
+        per = VALU_HALF_RATE_SHARE * VALU_HALF_RATE_CYCLES + (1 - VALU_HALF_RATE_SHARE) * VALU_FULL_RATE_CYCLES
+        v_cycles = valu * per / (4 * cus)
+        levels["valu"] = {"achieved": round(v_cycles / 1e6, 3), "peak": round(cyc / 1e6, 3), "unit": "Mcycles per SIMD",
+                          "frac": round(v_cycles / cyc, 4), "valu_wave_instructions_per_launch": int(valu),
+                          "what": f"SQ_INSTS_VALU x {per:.2f} cycles ({VALU_HALF_RATE_SHARE:.0%} half-rate instructions, "
+                                  "tools/ubench_valu.hip) per SIMD against the kernel's cycles"}
+    out = {"kernel_ms": round(kernel_ms, 4), "clock_ghz": round(clk / 1e9, 3) if clk else None, "traffic": int(hbm) if hbm else None,
+           "levels": levels}
+    if levels:
+        b = max(levels, key=lambda k: levels[k]["frac"])
+        out.update({"bound": b, "achieved": levels[b]["achieved"], "peak": levels[b]["peak"], "unit": levels[b]["unit"],
+                    "frac": levels[b]["frac"]})
+    else:
+        out.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
+    if alg_bytes is not None:
+        a = alg_bytes / t / 1e9
+        out["algorithmic"] = {"bytes_per_launch": int(alg_bytes), "rate_gbs": round(a, 1),
+                              "over_hbm_peak": round(a / HBM_PEAK_GBS, 4),
+                              "what": "SURVEY 8(d): 32 B per node visit + 4C per leaf + 4 B/px; mostly served by LDS/L1/L2, "
+                                      "so this rate is not bounded by HBM"}
+    return out
+
+
+if __name__ == "__main__":
+    # usage: tools/roofline.py <dir with rocprofv3 csv trees> <kernel substring> <kernel_ms>
+    name, vals = parse_counters(sys.argv[1], sys.argv[2])
+    print(json.dumps({"kernel": name, "counters": vals, "roofline": model(vals, float(sys.argv[3]))}, indent=1))

@@ -22,12 +22,14 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 enum Op { FMA = 0, PK_FMA, CVT_F32_I32, CVT_FLR_I32_F32, ADD_U32, PERM_B32, CNDMASK, MAD_U32_U24, LSHL_ADD,
-          CMP_SGPR, CNDMASK_SGPR, MUL_U32_U24, ADD_LSHL, OR3, BFE_I32, LSHLREV, MAX_I32, PK_MUL, MOV, FLOOR_F32, MED3_I32, PK_ADD_I16, N_OPS };
+          CMP_SGPR, CNDMASK_SGPR, MUL_U32_U24, ADD_LSHL, OR3, BFE_I32, LSHLREV, MAX_I32, PK_MUL, MOV, FLOOR_F32, MED3_I32, PK_ADD_I16, CNDMASK_SDWA, ADD_F32, MUL_F32, CMP_CND_VCC, CMP_CND_SGPR, CND_VCC_NEWDST, CND_E64_VCC, N_OPS };
 static const char *kOpName[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_i32", "v_cvt_flr_i32_f32", "v_add_u32",
                                      "v_perm_b32", "v_cndmask_b32(vcc)", "v_mad_u32_u24", "v_lshl_add_u32",
                                      "v_cmp_gt_u32 -> sgpr", "v_cndmask_b32(sgpr)", "v_mul_u32_u24", "v_add_lshl_u32", "v_or3_b32",
                                      "v_bfe_i32", "v_lshlrev_b32", "v_max_i32", "v_pk_mul_f32", "v_mov_b32", "v_floor_f32",
-                                     "v_med3_i32", "v_pk_add_i16"};
+                                     "v_med3_i32", "v_pk_add_i16", "v_cndmask_b32_sdwa(vcc)", "v_add_f32", "v_mul_f32",
+                                     "v_cmp->vcc + v_cndmask(vcc) [pair]", "v_cmp->sgpr + v_cndmask(sgpr) [pair]",
+                                     "v_cndmask_b32(vcc) dst!=src", "v_cndmask_b32_e64(vcc)"};
 
 #define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 
@@ -48,6 +50,9 @@ __global__ __launch_bounds__(1024) void k_valu(int iters, unsigned long long *st
     const float b = seed * 0.999f, c = seed * 0.001f;
     const f2 b2 = {b, b}, c2 = {c, c};
     const uint32_t ub = (uint32_t)(seed * 1000.f) | 1u;
+    // the kernel must own VCC (inline asm below reads it without telling the compiler: in a kernel that never mentions
+    // VCC the register is not reserved, and v_cndmask ... vcc then took 19.5 cycles, an artefact)
+    asm volatile("v_cmp_gt_u32 vcc, %0, %1" :: "v"(u[0]), "v"(ub) : "vcc");
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -137,8 +142,36 @@ __global__ __launch_bounds__(1024) void k_valu(int iters, unsigned long long *st
 #define S(k) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(u[k]) : "v"(ub), "v"(ub));
                 REP8(S)
 #undef S
-            } else {
+            } else if (OP == PK_ADD_I16) {
 #define S(k) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(u[k]) : "v"(ub));
+                REP8(S)
+#undef S
+            } else if (OP == CNDMASK_SDWA) {
+#define S(k) asm volatile("v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(u[k]) : "v"(ub));
+                REP8(S)
+#undef S
+            } else if (OP == ADD_F32) {
+#define S(k) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+                REP8(S)
+#undef S
+            } else if (OP == MUL_F32) {
+#define S(k) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                REP8(S)
+#undef S
+            } else if (OP == CMP_CND_VCC) {
+#define S(k) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[k]) : "v"(ub) : "vcc");
+                REP8(S)
+#undef S
+            } else if (OP == CMP_CND_SGPR) {
+#define S(k) asm volatile("v_cmp_gt_u32_e64 %1, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(u[k]), "=&s"(m[k]) : "v"(ub));
+                REP8(S)
+#undef S
+            } else if (OP == CND_VCC_NEWDST) {
+#define S(k) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(u[k]) : "v"(ub), "v"(ub));
+                REP8(S)
+#undef S
+            } else {
+#define S(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(u[k]) : "v"(ub));
                 REP8(S)
 #undef S
             }
@@ -246,5 +279,12 @@ int main(int argc, char **argv)
     run_op<FLOOR_F32>(cus, iters, d_st, d_wh);
     run_op<MED3_I32>(cus, iters, d_st, d_wh);
     run_op<PK_ADD_I16>(cus, iters, d_st, d_wh);
+    run_op<CNDMASK_SDWA>(cus, iters, d_st, d_wh);
+    run_op<ADD_F32>(cus, iters, d_st, d_wh);
+    run_op<MUL_F32>(cus, iters, d_st, d_wh);
+    run_op<CMP_CND_VCC>(cus, iters, d_st, d_wh);
+    run_op<CMP_CND_SGPR>(cus, iters, d_st, d_wh);
+    run_op<CND_VCC_NEWDST>(cus, iters, d_st, d_wh);
+    run_op<CND_E64_VCC>(cus, iters, d_st, d_wh);
     return 0;
 }
