@@ -8,9 +8,9 @@
 //
 // Here everything stays on the device and is bitwise reproducible:
 //   * round r is ONE launch; every workgroup first rebuilds the previous round's means from that
-//     round's per-workgroup partial sums (read in workgroup order, so all workgroups get identical
-//     values), then accumulates its pixels with fixed-order wave reductions -- no atomics, so no
-//     order dependence (the reference's fp64 atomics make its last bits run-dependent);
+//     round's per-workgroup partial sums (one per lane, added by a fixed shuffle tree, so all workgroups
+//     get identical values), then accumulates its pixels with fixed-order wave reductions -- no atomics,
+//     so no order dependence (the reference's fp64 atomics make its last bits run-dependent);
 //   * kernel boundaries are the only inter-workgroup hand-off (no in-kernel fences needed).
 
 #include <hip/hip_runtime.h>
@@ -52,26 +52,31 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_round(const uint16_t 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- means entering this round = means[round-1 slot] + shift of round-1 (mean_shift.py:54-57) ----
-    if (tid < L) {
-        double mx = 0.0, my = 0.0;
-        if (round > 0) {
-            const double *prev = ws + ms_means_off(round - 1, L) + (size_t)tid * 2;
-            const double *part = ws + ms_part_off(num_rounds, L, (round - 1) & 1);
-            double sx = 0.0, sy = 0.0, sw = 0.0;
-            for (int b = 0; b < kMsBlocks; ++b) {   // workgroup order: identical in every workgroup
-                const double *p = part + ((size_t)b * L + tid) * 3;
-                sx += p[0]; sy += p[1]; sw += p[2];
+    // The previous round left one partial sum per workgroup; lane b of a wave fetches workgroup b's and a fixed
+    // shuffle tree adds them (same inputs, same tree in every workgroup: identical means everywhere).  An earlier
+    // version added the 64 partials one after the other in one lane of every workgroup: 64 dependent round trips to L2
+    // made a round cost 13 us for 2 us of work (profiles/r02_pipeline_kernel_stats.csv).
+    static_assert(kMsBlocks == 64, "one partial per lane");
+    if (round > 0) {
+        const double *part = ws + ms_part_off(num_rounds, L, (round - 1) & 1);
+        for (int c = wave; c < L; c += kMsWaves) {
+            const double *p = part + ((size_t)lane * L + c) * 3;
+            const double sx = wave_sum(p[0]), sy = wave_sum(p[1]), sw = wave_sum(p[2]);
+            if (lane == 0) {
+                const double *prev = ws + ms_means_off(round - 1, L) + (size_t)c * 2;
+                s_means[c][0] = prev[0] + sx / sw;      // 0/0 = NaN for a class without pixels, as in the reference
+                s_means[c][1] = prev[1] + sy / sw;
             }
-            mx = prev[0] + sx / sw;                 // 0/0 = NaN for a class without pixels, as in the reference
-            my = prev[1] + sy / sw;
         }
-        s_means[tid][0] = mx;
-        s_means[tid][1] = my;
-        if (blockIdx.x == 0) {
-            double *cur = ws + ms_means_off(round, L) + (size_t)tid * 2;
-            cur[0] = mx; cur[1] = my;
-            if (round == num_rounds) { means_out[tid * 2] = mx; means_out[tid * 2 + 1] = my; }
-        }
+    } else if (tid < L) {
+        s_means[tid][0] = 0.0;
+        s_means[tid][1] = 0.0;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < L) {
+        double *cur = ws + ms_means_off(round, L) + (size_t)tid * 2;
+        cur[0] = s_means[tid][0]; cur[1] = s_means[tid][1];
+        if (round == num_rounds) { means_out[tid * 2] = s_means[tid][0]; means_out[tid * 2 + 1] = s_means[tid][1]; }
     }
     if (round == num_rounds) return;
     for (int i = tid; i < kMsWaves * kMsMaxClasses * 3; i += kMsThreads) (&s_acc[0][0][0])[i] = 0.0;

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         if (FULLROWS && tw > 0) {
             bool mine = false;
             for (int sub = 0; sub < rows_per_wave; ++sub) {
-                const int ly = (int)(ty * tile_rows + (uint32_t)sub * kWaves + wave);
+                const uint32_t trow = (uint32_t)sub * kWaves + wave;
+                if (trow >= tile_rows) break;
+                const int ly = (int)(ty * tile_rows + trow);
                 if (ly < a.Hl && lx < a.Wl) {
                     const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
                     const uint32_t d = *reinterpret_cast<const uint16_t *>(
@@ -340,8 +342,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
         for (int sub = 0; sub < kMaxRowsPerWave; ++sub) {
             if (sub >= rows_per_wave || !compact) break;
             // rows of the workgroup's waves are interleaved: at any time they cover adjacent rows
-            const int ly = (int)(ty * tile_rows + (uint32_t)sub * kWaves + wave);
-            bool ok = ly < a.Hl && lx < a.Wl;
+            const uint32_t trow = (uint32_t)sub * kWaves + wave;
+            const int ly = (int)(ty * tile_rows + trow);
+            bool ok = trow < tile_rows && ly < a.Hl && lx < a.Wl;
             if (ok) {
                 const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
                 if (a.filter_class != -1) ok = (int)a.filter[i] == a.filter_class;
@@ -352,11 +355,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
                 if (!ok && a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
             }
             const unsigned long long b = __ballot(ok);
-            if (lane == 0) s_cnt[(uint32_t)sub * kWaves + wave] = (uint32_t)__popcll(b);
+            if (lane == 0 && trow < tile_rows) s_cnt[trow] = (uint32_t)__popcll(b);
             my_rank[sub] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
             my_valid |= ok ? 1u << sub : 0u;
         }
-        uint32_t n_valid = BLOCK * (uint32_t)rows_per_wave;
+        uint32_t n_valid = 64u * tile_rows;
         if (compact) {
             __syncthreads();
             n_valid = 0u;
@@ -376,12 +379,14 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
             __syncthreads();
         }
 
+        // pixel slots of the tile, row-major (row << 6 | column), 64 per wave step; uncompacted, the rows of the waves
+        // are interleaved
         for (uint32_t first = wave * 64u; first < n_valid; first += BLOCK) {
-            // uncompacted: pass `first / BLOCK` over the wave's own rows (rows of the workgroup's waves are interleaved)
-            uint32_t entry = (((first / BLOCK) * kWaves + wave) << 6) | (uint32_t)lane;
+            const uint32_t slot = first + (uint32_t)lane;
+            uint32_t entry = slot;
             if (compact) {
-                if (first + (uint32_t)lane >= n_valid) continue;
-                entry = px_list[first + (uint32_t)lane];
+                if (slot >= n_valid) continue;
+                entry = px_list[slot];
             }
             const int ly = (int)(ty * tile_rows + (entry >> 6));
             const int px = (int)(tx * 64u + (entry & 63u));
@@ -781,6 +786,7 @@ std::mutex g_sched_mu;
 std::map<std::pair<int, void *>, int> g_sched_slot;
 std::map<int, unsigned int *> g_sched_base;     // device -> address of g_sched on that device
 int g_compaction = -1;                          // -1: filtered launches compact their pixels; 0: never
+int g_group = 0;                                // 0: trees per lane chosen by forest size; 1..4: forced (rdf_set_group)
 int g_sched_mode = -1;                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic, 2 one tile per workgroup
 
 int sched_mode()
@@ -913,9 +919,12 @@ template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
 int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
     if (BLOCK == 256 && !STATS) {
-        if (a.T == 1) return launch_group<256, PACKED, CMAX, false, FULLROWS, 1>(a, lds_bytes, cus, st);
-        if (a.T == 2) return launch_group<256, PACKED, CMAX, false, FULLROWS, 2>(a, lds_bytes, cus, st);
-        if (a.T == 3 || a.T == 6) return launch_group<256, PACKED, CMAX, false, FULLROWS, 3>(a, lds_bytes, cus, st);
+        // trees a lane walks interleaved; rdf_set_group overrides the choice by forest size (any width is correct for any
+        // forest: slots beyond the last tree idle)
+        const int g = g_group > 0 ? g_group : (a.T == 1 ? 1 : a.T == 2 ? 2 : (a.T == 3 || a.T == 6) ? 3 : 4);
+        if (g == 1) return launch_group<256, PACKED, CMAX, false, FULLROWS, 1>(a, lds_bytes, cus, st);
+        if (g == 2) return launch_group<256, PACKED, CMAX, false, FULLROWS, 2>(a, lds_bytes, cus, st);
+        if (g == 3) return launch_group<256, PACKED, CMAX, false, FULLROWS, 3>(a, lds_bytes, cus, st);
     }
     return launch_group<BLOCK, PACKED, CMAX, STATS, FULLROWS, kGroup>(a, lds_bytes, cus, st);
 }
@@ -1272,6 +1281,7 @@ void rdf_set_block_threads(int threads) { g_block_threads = threads; }
 void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
 void rdf_set_compaction(int mode) { g_compaction = mode; }
 void rdf_set_halo(int pixels) { g_halo = pixels; }
+void rdf_set_group(int trees) { g_group = trees; }
 void rdf_set_lds_levels(int levels) { g_lds_levels = levels; }
 void rdf_set_stage_vec(int on) { g_stage_vec = on; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }

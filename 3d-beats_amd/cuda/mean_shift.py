@@ -19,8 +19,10 @@ class MeanShift:
         self._ws = None
         self._key = None
 
-    def run_device(self, num_rounds, labels, num_labels, variances):
-        """Same as run() but leaves the means on the device (DeviceArray float64 [num_labels, 2])."""
+    def run_device(self, num_rounds, labels, num_labels, variances, out=None):
+        """Same as run() but leaves the means on the device (DeviceArray float64 [num_labels, 2]); `out` = a float64
+        device array of 2 * num_labels elements that receives them instead of self.means (HandPipeline's result
+        buffer: no copy afterwards)."""
         dim_y, dim_x = labels.shape[-2:]
         key = (int(num_labels), int(num_rounds))
         if self._key != key:
@@ -28,12 +30,14 @@ class MeanShift:
             nbytes = int(self._lib.rdf_mean_shift_workspace_bytes(int(num_labels), int(num_rounds)))
             self._ws = DeviceArray((max(nbytes, 8),), np.uint8)
             self._key = key
+        dst = self.means if out is None else out
+        assert int(np.prod(dst.shape)) == 2 * int(num_labels) and np.dtype(dst.dtype) == np.float64
         rc = self._lib.rdf_mean_shift(device_ptr(labels), int(dim_x), int(dim_y), int(num_labels),
-                                      device_ptr(variances), int(num_rounds), self.means.ptr, self._ws.ptr,
+                                      device_ptr(variances), int(num_rounds), dst.ptr, self._ws.ptr,
                                       self._rt.stream())
         _lib.check(self._lib, rc, "rdf_mean_shift")
-        self.means.mark_dirty()
-        return self.means
+        dst.mark_dirty()
+        return dst
 
     def run(self, num_rounds, labels, num_labels, variances):
         return self.run_device(num_rounds, labels, num_labels, variances).get()

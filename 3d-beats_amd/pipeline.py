@@ -125,7 +125,7 @@ class HandPipeline:
 
         means = self.mean_shift.run_device(self.mean_shift_rounds,
                                            self.labels_image.cu().reshape((1, self.LABELS_DIM_Y, self.LABELS_DIM_X)),
-                                           self._L, self.mean_shift_variances)
+                                           self._L, self.mean_shift_variances, out=self._result[:self._L * 2])
         fx, fy, ppx, ppy = self.intrinsics
         heights = self._result[self._L * 2:]
         # z is looked up in the ORIGINAL depth frame (3d_bz.py:515), not the stencilled / flipped one
@@ -133,5 +133,4 @@ class HandPipeline:
                                              device_ptr(depth_image.cu()), self.DIM_X, self.DIM_Y, self.LABELS_REDUCE,
                                              fx, fy, ppx, ppy, self._plane.ptr, heights.ptr, self._rt.stream())
         _lib.check(self._lib, rc, "rdf_fingertip_heights")
-        self._result[:self._L * 2].copy_from(means.reshape(self._L * 2))
         self._result.mark_dirty()

@@ -280,6 +280,7 @@ void rdf_set_rows_per_wave(int rows);    /* label rows per wave in a tile: 1, 2 
 void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (24) */
 void rdf_set_lds_levels(int levels);     /* top levels of every tree pinned in LDS (the depth tile then gets the rest of
                                             the LDS budget instead of half of it); -1 = fill what the tile leaves */
+void rdf_set_group(int trees);           /* trees a lane walks interleaved: 1..4, 0 = by forest size (256-thread workgroups only) */
 void rdf_set_stage_vec(int on);          /* tile staging with 16-byte loads where alignment allows: 1/-1 (default) on, 0 off */
 void rdf_set_force_exact(int on);        /* test knob: rdf_forest_pack flags every node for the IEEE-divide path */
 

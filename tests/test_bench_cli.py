@@ -1,0 +1,58 @@
+"""bench.py's contract with the driver, rehearsed on the one GPU of the test box: the N = 1 line carries the roofline and
+the legs, and the N > 1 code path (two ranks over gloo sharing the GPU: same control flow as RCCL ranks on distinct
+GPUs) gathers, verifies the gather and reports what a driver needs to check the run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_has_roofline_and_legs(tmp_path):
+    env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--frames", "8",
+                        "--depth", "12", "--no-counters", "--no-cfg5", "--cpu-seconds", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "Mpix/s" and d["value"] > 0
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "levels", "algorithmic"} <= set(d["roofline"])
+    assert d["roofline"]["algorithmic"]["bytes_per_launch"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and "differ in 0 pixels" in d["cpu_baseline"]["sample"]
+    assert d["cfg2_single_frame"]["kernel_ms"] > 0 and d["cfg3_layered_run"]["ms_per_frame_wall"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["p2p", "rccl"])
+def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
+    env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", "6", "--depth", "12", "--backend", "gloo", "--gather", gather, "--reserve-cus", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["gather_check"] == "ok"
+    dd = d["distributed"]
+    assert dd["rccl_ranks"] == 2 and len(dd["devices"]) == 2 and dd["kernel_only_ms"] > 0 and dd["value_kernel_only"] >= d["value"] * 0.5
+    assert dd["distinct_devices"] == 1                      # both ranks share the test box's GPU; 8 on the driver's node
+    assert all(m["gather_check"] == "ok" for m in dd["gather_modes"].values())
+    assert ("p2p" in d["config"]["gather"]) == (gather == "p2p")

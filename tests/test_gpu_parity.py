@@ -412,6 +412,7 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
             lib.rdf_set_halo(int(rng.choice([-1, 0, 5, 16, 33, 48])))
             lib.rdf_set_lds_levels(int(rng.choice([-1, -1, 0, 2, 9])))
             lib.rdf_set_stage_vec(int(rng.choice([-1, -1, 0])))
+            lib.rdf_set_group(int(rng.choice([0, 0, 1, 2, 3, 4])))
             lib.rdf_set_rows_per_wave(int(rng.choice([0, 1, 2, 4])))
             lib.rdf_set_scheduler(int(rng.choice([-1, 0, 1, 2])))
             lib.rdf_set_lds_budget_bytes(int(rng.choice([0, 1, 9000, 40000, 120000])))
@@ -425,6 +426,7 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
         lib.rdf_set_halo(-1)
         lib.rdf_set_lds_levels(-1)
         lib.rdf_set_stage_vec(-1)
+        lib.rdf_set_group(0)
         lib.rdf_set_rows_per_wave(0)
         lib.rdf_set_scheduler(-1)
         lib.rdf_set_lds_budget_bytes(0)

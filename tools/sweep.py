@@ -51,7 +51,7 @@ def main():
         f2d = (((xx // 32 + yy // 32) % a.filter) == 0).astype(np.uint16)
         filt = rdf.to_device(np.broadcast_to(f2d, (host.shape[0],) + f2d.shape).copy())
     lib.rdf_set_compaction(0 if a.no_compaction else -1)
-    combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]   # block:lds[:rows_per_wave[:halo[:lds_levels[:stage_vec]]]]
+    combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]   # block:lds[:rows_per_wave[:halo[:lds_levels[:stage_vec[:group]]]]]
     res = {c: [] for c in combos}
     ref = None
     for r in range(a.rounds + 1):
@@ -62,6 +62,7 @@ def main():
             lib.rdf_set_halo(c[3] if len(c) > 3 else -1)
             lib.rdf_set_lds_levels(c[4] if len(c) > 4 else -1)
             lib.rdf_set_stage_vec(c[5] if len(c) > 5 else -1)
+            lib.rdf_set_group(c[6] if len(c) > 6 else 0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(a.reps):
@@ -77,7 +78,7 @@ def main():
     npx = a.frames * a.height * a.width
     for c in combos:
         v = np.array(res[c])
-        print(f"block {c[0]:5d} lds {c[1]:7d} rpw {c[2] if len(c) > 2 else 0} halo {c[3] if len(c) > 3 else -1:3d} levels {c[4] if len(c) > 4 else -1:2d} vec {c[5] if len(c) > 5 else -1:2d}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
+        print(f"block {c[0]:5d} lds {c[1]:7d} rpw {c[2] if len(c) > 2 else 0} halo {c[3] if len(c) > 3 else -1:3d} levels {c[4] if len(c) > 4 else -1:2d} vec {c[5] if len(c) > 5 else -1:2d} group {c[6] if len(c) > 6 else 0}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
               f"{npx / np.median(v) / 1e3:8.1f} Mpix/s", flush=True)
 
 
