@@ -6,33 +6,25 @@
 // round zero-fills the sums, launches, copies sums and means to the host, divides, adds and copies
 // the means back (12 transfers for 6 rounds); heights: src/3d_bz.py:503-522 on the host.
 //
-// Here everything stays on the device and is bitwise reproducible:
-//   * round r is ONE launch; every workgroup first rebuilds the previous round's means from that
-//     round's per-workgroup partial sums (one per lane, added by a fixed shuffle tree, so all workgroups
-//     get identical values), then accumulates its pixels with fixed-order wave reductions -- no atomics,
-//     so no order dependence (the reference's fp64 atomics make its last bits run-dependent);
-//   * kernel boundaries are the only inter-workgroup hand-off (no in-kernel fences needed).
+// Here everything stays on the device, in ONE launch, and is bitwise reproducible: one workgroup per class lists the
+// class's pixels in LDS once and runs every round on that list with fixed-order sums -- no atomics, so no order
+// dependence (the reference's fp64 atomics make its last bits run-dependent), and no hand-off between workgroups.
 
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/rdf_hip.h"
 
 namespace {
 
-constexpr int kMsBlocks = 64;      // workgroups per round (fixed: it defines the summation order)
 constexpr int kMsThreads = 1024;
 constexpr int kMsWaves = kMsThreads / 64;
 constexpr int kMsMaxClasses = 64;
-constexpr uint32_t kNoLabel = 65535u;
-
-// workspace layout (doubles): means[rounds + 1][L][2] (slot 0 = start = zeros) | partials[2][kMsBlocks][L][3]
-__host__ __device__ inline size_t ms_means_off(int slot, int L) { return (size_t)slot * L * 2; }
-__host__ __device__ inline size_t ms_part_off(int rounds, int L, int parity)
-{
-    return (size_t)(rounds + 1) * L * 2 + (size_t)parity * kMsBlocks * L * 3;
-}
+constexpr uint32_t kMsListCap = 36864;   // pixels of one class kept in LDS (147 456 B of the CU's 160 KB)
+constexpr int kMsSteps = 13;             // 16 waves x 13 steps x 512 pixels = 106 496 >= the app's 424 x 240 label map
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -41,92 +33,135 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// round == 0: centroid sums (mean_shift.cu:32-35); round >= 1: kernel-weighted shift sums (:36-47).
-// round == num_rounds: no pixel pass, only the final means.
-__global__ __launch_bounds__(kMsThreads) void k_mean_shift_round(const uint16_t *labels, int dim_x, int dim_y, int L,
-                                                                 const float *variances, int round, int num_rounds,
-                                                                 double *ws, double *means_out)
+// Sum of every thread's (a, b, c) in a fixed order: shuffle tree inside a wave, then the waves one after the other.
+// Every thread returns with the totals in tot[0..2].
+__device__ __forceinline__ void block_sum3(double a, double b, double c, double (*s_red)[3], double *tot)
 {
-    __shared__ double s_means[kMsMaxClasses][2];
-    __shared__ double s_acc[kMsWaves][kMsMaxClasses][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    __syncthreads();                       // the previous call's readers are done with s_red
+    if (lane == 0) { s_red[wave][0] = a; s_red[wave][1] = b; s_red[wave][2] = c; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+    for (int w = 0; w < kMsWaves; ++w) { ta += s_red[w][0]; tb += s_red[w][1]; tc += s_red[w][2]; }   // broadcast reads
+    tot[0] = ta; tot[1] = tb; tot[2] = tc;
+}
+
+// All rounds of one class in ONE workgroup, all classes in one launch: classes never interact (mean_shift.cu:3-48 sums
+// per class), so no round needs anything from another workgroup.  The workgroup lists its class's pixels once, in pixel
+// order, in LDS (x | y << 16) and then iterates over the list: round 0 = centroid (:32-35), rounds >= 1 = kernel-weighted
+// shift (:36-47), means += sums[:2] / sums[2] after each (mean_shift.py:54-57).  A class with more than kMsListCap
+// pixels keeps its first kMsListCap in the list and rescans the label image from there on every round.  Every sum is
+// taken in a fixed order (thread-strided partial sums, shuffle tree, waves in order): bitwise reproducible.
+// An earlier version ran one launch per round over 64 workgroups with a cross-workgroup partial-sum hand-off at every
+// kernel boundary: 7 launches, 74 us for the app's 424x240 label map (profiles/r02_pipeline_kernel_stats_before.csv).
+__global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t *labels, int dim_x, int dim_y, int L,
+                                                                 const float *variances, int num_rounds, double *means_out)
+{
+    extern __shared__ uint32_t s_list[];
+    __shared__ double s_red[kMsWaves][3];
+    __shared__ uint32_t s_wave_cnt[kMsWaves];
+    __shared__ uint32_t s_rescan_from;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t want = blockIdx.x + 1u;
+    const uint32_t n_px = (uint32_t)dim_x * (uint32_t)dim_y;
 
-    // ---- means entering this round = means[round-1 slot] + shift of round-1 (mean_shift.py:54-57) ----
-    // The previous round left one partial sum per workgroup; lane b of a wave fetches workgroup b's and a fixed
-    // shuffle tree adds them (same inputs, same tree in every workgroup: identical means everywhere).  An earlier
-    // version added the 64 partials one after the other in one lane of every workgroup: 64 dependent round trips to L2
-    // made a round cost 13 us for 2 us of work (profiles/r02_pipeline_kernel_stats.csv).
-    static_assert(kMsBlocks == 64, "one partial per lane");
-    if (round > 0) {
-        const double *part = ws + ms_part_off(num_rounds, L, (round - 1) & 1);
-        for (int c = wave; c < L; c += kMsWaves) {
-            const double *p = part + ((size_t)lane * L + c) * 3;
-            const double sx = wave_sum(p[0]), sy = wave_sum(p[1]), sw = wave_sum(p[2]);
-            if (lane == 0) {
-                const double *prev = ws + ms_means_off(round - 1, L) + (size_t)c * 2;
-                s_means[c][0] = prev[0] + sx / sw;      // 0/0 = NaN for a class without pixels, as in the reference
-                s_means[c][1] = prev[1] + sy / sw;
-            }
-        }
-    } else if (tid < L) {
-        s_means[tid][0] = 0.0;
-        s_means[tid][1] = 0.0;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < L) {
-        double *cur = ws + ms_means_off(round, L) + (size_t)tid * 2;
-        cur[0] = s_means[tid][0]; cur[1] = s_means[tid][1];
-        if (round == num_rounds) { means_out[tid * 2] = s_means[tid][0]; means_out[tid * 2 + 1] = s_means[tid][1]; }
-    }
-    if (round == num_rounds) return;
-    for (int i = tid; i < kMsWaves * kMsMaxClasses * 3; i += kMsThreads) (&s_acc[0][0][0])[i] = 0.0;
-    __syncthreads();
-
-    // ---- this workgroup's pixels: a contiguous slab, 64 consecutive pixels per wave step ----
-    const long long n_px = (long long)dim_x * dim_y;
-    const long long per_block = (n_px + kMsBlocks - 1) / kMsBlocks;
-    const long long begin = per_block * blockIdx.x;
-    const long long end = begin + per_block < n_px ? begin + per_block : n_px;
-    for (long long base = begin + (long long)wave * 64; base < end; base += kMsThreads) {
-        const long long p = base + lane;
-        uint32_t l = 0u;
-        double cx = 0.0, cy = 0.0, cw = 0.0;
-        if (p < end) {
-            l = labels[p];
-            if (l != 0u && l != kNoLabel && l <= (uint32_t)L) {
-                const double x = (double)(int)(p % dim_x), y = (double)(int)(p / dim_x);
-                if (round == 0) {
-                    cx = x; cy = y; cw = 1.0;
-                } else {
-                    const double dx = x - s_means[l - 1][0], dy = y - s_means[l - 1][1];
-                    const double dist_sq = (dx * dx) + (dy * dy);
-                    const float vf = variances[l - 1];
-                    const double v_2 = (double)(vf * vf);          // float product, as mean_shift.cu:42
-                    const double w = exp(-dist_sq / (2 * v_2));
-                    cx = dx * w; cy = dy * w; cw = w;
-                }
+    // ---- list this class's pixels in pixel order.  A wave takes kMsSteps x 512 consecutive pixels per batch, eight per
+    // lane and step (one 16-byte load; all of a batch's loads are in flight together and the labels stay in registers
+    // between counting and writing); list positions follow (batch, wave, step, lane, pixel) = pixel order, from ballots
+    // and popcounts, so the order does not depend on timing.  The first pixel that does not fit marks where the
+    // rounds rescan the image from. ----
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(labels) & 15u) == 0u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (tid == 0) s_rescan_from = n_px;
+    uint32_t n_class = 0;
+    for (uint32_t batch0 = 0; batch0 < n_px; batch0 += kMsWaves * kMsSteps * 512u) {
+        const uint32_t wbase = batch0 + (uint32_t)wave * (kMsSteps * 512u);
+        uint32_t m[kMsSteps];        // bit j: pixel j of this lane's eight is of the class
+#pragma unroll
+        for (int k = 0; k < kMsSteps; ++k) {
+            const uint32_t p0 = wbase + ((uint32_t)k * 64u + (uint32_t)lane) * 8u;
+            uint32_t bits = 0u;
+            if (p0 + 8u <= n_px && vec_ok) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(labels + p0);
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bits |= ((w4[q] & 0xFFFFu) == want ? 1u << (2 * q) : 0u) | ((w4[q] >> 16) == want ? 2u << (2 * q) : 0u);
             } else {
-                l = 0u;
+                for (int j = 0; j < 8; ++j)
+                    if (p0 + (uint32_t)j < n_px && labels[p0 + j] == want) bits |= 1u << j;
+            }
+            m[k] = bits;
+        }
+        uint32_t before[kMsSteps];   // pixels of the class in this wave's batch before this lane's eight of step k
+        uint32_t wave_total = 0u;
+#pragma unroll
+        for (int k = 0; k < kMsSteps; ++k) {
+            uint32_t pre = wave_total;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long bl = __ballot((m[k] >> j) & 1u);
+                wave_total += (uint32_t)__popcll(bl);
+                pre += (uint32_t)__popcll(bl & lt_mask);       // lower lanes' pixel j ...
+            }
+            // ... counted every lower lane's eight pixels bit by bit: exactly the pixels before this lane's first
+            before[k] = pre;
+        }
+        __syncthreads();             // the previous batch's s_wave_cnt has been read
+        if (lane == 0) s_wave_cnt[wave] = wave_total;
+        __syncthreads();
+        uint32_t pos = n_class, batch_total = 0u;
+        for (int w = 0; w < kMsWaves; ++w) {
+            if (w < wave) pos += s_wave_cnt[w];
+            batch_total += s_wave_cnt[w];
+        }
+#pragma unroll
+        for (int k = 0; k < kMsSteps; ++k) {
+            uint32_t at = pos + before[k];
+            const uint32_t p0 = wbase + ((uint32_t)k * 64u + (uint32_t)lane) * 8u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if ((m[k] >> j) & 1u) {
+                    const uint32_t p = p0 + (uint32_t)j;
+                    if (at < kMsListCap) s_list[at] = (p % (uint32_t)dim_x) | ((p / (uint32_t)dim_x) << 16);
+                    else if (at == kMsListCap) s_rescan_from = p;
+                    ++at;
+                }
             }
         }
-        unsigned long long present = 0ull;   // classes seen by this wave step
-        for (int c = 0; c < L; ++c) {
-            if (__any(l == (uint32_t)(c + 1))) present |= 1ull << c;
-        }
-        for (int c = 0; c < L; ++c) {
-            if (!((present >> c) & 1ull)) continue;
-            const bool mine = l == (uint32_t)(c + 1);
-            const double sx = wave_sum(mine ? cx : 0.0), sy = wave_sum(mine ? cy : 0.0), sw = wave_sum(mine ? cw : 0.0);
-            if (lane == 0) { s_acc[wave][c][0] += sx; s_acc[wave][c][1] += sy; s_acc[wave][c][2] += sw; }
-        }
+        n_class += batch_total;
     }
     __syncthreads();
-    if (tid < L * 3) {
-        const int c = tid / 3, k = tid % 3;
-        double s = 0.0;
-        for (int w = 0; w < kMsWaves; ++w) s += s_acc[w][c][k];
-        ws[ms_part_off(num_rounds, L, round & 1) + ((size_t)blockIdx.x * L + c) * 3 + k] = s;
+    const uint32_t n_list = min(n_class, kMsListCap), rescan_from = s_rescan_from;
+
+    double mx = 0.0, my = 0.0;
+    const float vf = variances ? variances[blockIdx.x] : 0.0f;
+    const double v_2 = (double)(vf * vf);          // float product, as mean_shift.cu:42
+    for (int round = 0; round < num_rounds; ++round) {
+        double sx = 0.0, sy = 0.0, sw = 0.0;
+        auto term = [&](double x, double y) {
+            if (round == 0) {
+                sx += x; sy += y; sw += 1.0;
+            } else {
+                const double dx = x - mx, dy = y - my;
+                const double dist_sq = (dx * dx) + (dy * dy);
+                const double w = exp(-dist_sq / (2 * v_2));
+                sx += dx * w; sy += dy * w; sw += w;
+            }
+        };
+        for (uint32_t i = tid; i < n_list; i += kMsThreads) {
+            const uint32_t e = s_list[i];
+            term((double)(int)(e & 0xFFFFu), (double)(int)(e >> 16));
+        }
+        for (uint32_t p = rescan_from + tid; p < n_px; p += kMsThreads)
+            if (labels[p] == want) term((double)(int)(p % (uint32_t)dim_x), (double)(int)(p / (uint32_t)dim_x));
+        double tot[3];
+        block_sum3(sx, sy, sw, s_red, tot);
+        mx = mx + tot[0] / tot[2];                 // 0/0 = NaN for a class without pixels, as in the reference
+        my = my + tot[1] / tot[2];
     }
+    if (tid == 0) { means_out[blockIdx.x * 2] = mx; means_out[blockIdx.x * 2 + 1] = my; }
 }
 
 // Heights of the requested classes' modes above the calibrated plane (3d_bz.py:503-522):
@@ -164,26 +199,38 @@ extern "C" {
 
 size_t rdf_mean_shift_workspace_bytes(int num_classes, int num_rounds)
 {
-    if (num_classes < 0 || num_rounds < 0) return 0;
-    return (ms_part_off(num_rounds, num_classes, 0) + (size_t)2 * kMsBlocks * num_classes * 3) * sizeof(double);
+    (void)num_classes; (void)num_rounds;
+    return 0;      // every class iterates inside one workgroup: nothing is handed between workgroups any more
 }
 
 int rdf_mean_shift(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,
                    int num_rounds, double *means_out, void *workspace, void *stream)
 {
-    if (dim_x < 0 || dim_y < 0 || num_classes < 0 || num_classes > kMsMaxClasses || num_rounds < 0) return RDF_ERR_BAD_ARG;
+    (void)workspace;
+    if (dim_x < 0 || dim_y < 0 || dim_x > 65535 || dim_y > 65535 || num_classes < 0 || num_classes > kMsMaxClasses ||
+        num_rounds < 0)
+        return RDF_ERR_BAD_ARG;
     if (num_classes == 0) return RDF_OK;
-    if (!means_out || !workspace || (num_rounds > 0 && (!labels || !variances))) return RDF_ERR_NULL_PTR;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    double *ws = reinterpret_cast<double *>(workspace);
-    for (int r = 0; r <= num_rounds; ++r) {
-        const int blocks = r == num_rounds ? 1 : kMsBlocks;
-        hipLaunchKernelGGL(k_mean_shift_round, dim3(blocks), dim3(kMsThreads), 0, st, labels, dim_x, dim_y, num_classes,
-                           variances, r, num_rounds, ws, means_out);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
+    if ((long long)dim_x * dim_y >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    if (!means_out || (num_rounds > 0 && (!labels || !variances))) return RDF_ERR_NULL_PTR;
+    const int lds_bytes = (int)(kMsListCap * sizeof(uint32_t));
+    {   // more than 64 KB of dynamic LDS has to be allowed once per device
+        static std::mutex mu;
+        static unsigned long long allowed = 0ull;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev >= 64 || !((allowed >> dev) & 1ull)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mean_shift_fused),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return (int)e;
+            if (dev < 64) allowed |= 1ull << dev;
+        }
     }
-    return RDF_OK;
+    hipLaunchKernelGGL(k_mean_shift_fused, dim3((unsigned)num_classes), dim3(kMsThreads), lds_bytes,
+                       reinterpret_cast<hipStream_t>(stream), labels, dim_x, dim_y, num_classes, variances, num_rounds,
+                       means_out);
+    return (int)hipGetLastError();
 }
 
 int rdf_fingertip_heights(const double *means, int num_classes, const int *class_ids, int n_ids,

@@ -144,14 +144,14 @@ int rdf_eval_forest_stats(const uint16_t *depth, int n_img, int dim_x, int dim_y
  * ---- consumer of the composite label map ----
  * Per-class 2-D mean-shift mode finding.  Replaces the kernel `run` of src/cuda/mean_shift.cu:3-48
  * AND the host loop of src/cuda/mean_shift.py:35-59 (per round: zero the sums, launch, copy sums and
- * means to the host, divide, add, copy back): all `num_rounds` rounds run on the device, one launch
- * per round, no host round trip, bitwise-reproducible sums (no atomics).
+ * means to the host, divide, add, copy back): all `num_rounds` rounds of all classes run on the device
+ * in ONE launch (one workgroup per class), no host round trip, bitwise-reproducible sums (no atomics).
  *   labels     uint16 [dim_y][dim_x]; 0, 65535 and values > num_classes are ignored
  *   variances  float32 [num_classes] (device)
  *   means_out  float64 [num_classes][2] = (x, y) per class (device); NaN for a class without pixels,
  *              as the reference's 0/0
- *   workspace  rdf_mean_shift_workspace_bytes() bytes of device memory (contents irrelevant)
- * num_classes <= 64.
+ *   workspace  unused since round 2 (rdf_mean_shift_workspace_bytes() returns 0); may be NULL
+ * num_classes <= 64, dim_x and dim_y <= 65535.
  */
 size_t rdf_mean_shift_workspace_bytes(int num_classes, int num_rounds);
 int rdf_mean_shift(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,

@@ -45,7 +45,7 @@ def main():
         got = ms.run(rounds, dl, L, dv)
         out[f"{w}x{h}"] = {"device_us_per_run": round(dev * 1e6, 1), "with_result_copy_us": round(host * 1e6, 1),
                            "numpy_restatement_ms": round(cpu * 1e3, 2), "max_abs_diff_px": float(np.nanmax(np.abs(got - want))),
-                           "rounds": rounds, "classes": L, "launches": rounds + 1,
+                           "rounds": rounds, "classes": L, "launches": 1,
                            "label_bytes_per_round": h * w * 2}
     print(json.dumps({"mean_shift": out}))
 

@@ -81,3 +81,26 @@ def test_fingertip_heights_match_restatement(rdf, gpu_runtime):
     ok = ~np.isnan(want)
     assert np.allclose(got[ok], want[ok], rtol=1e-6, atol=1e-6), (got, want)
     assert np.isnan(want[[2, 4, 5]]).all() and not np.isnan(want[[0, 1, 3, 6]]).any()
+
+
+@pytest.mark.gpu
+def test_mean_shift_class_bigger_than_the_lds_list(rdf, gpu_runtime):
+    """A class with more pixels than one workgroup lists in LDS (36 864): the rest is rescanned from the label image every
+    round -- same means (1e-9 px), still bitwise reproducible; a neighbouring small class is unaffected."""
+    msmod = importlib.import_module("3d-beats_amd.cuda.mean_shift")
+    ms = msmod.MeanShift()
+    h, w, L = 240, 424, 3
+    rng = np.random.default_rng(12)
+    lab = np.full((h, w), 1, np.uint16)                 # class 1: ~97 000 pixels
+    lab[rng.random((h, w)) < 0.03] = 65535
+    lab[100:130, 200:260] = 2                           # class 2: 1 800 pixels; class 3 absent
+    lab[0, 0] = 0
+    var = np.array([80.0, 9.0, 5.0], np.float32)
+    dl, dv = rdf.to_device(lab[None]), rdf.to_device(var)
+    assert (lab == 1).sum() > 2 * 36864
+    for rounds in (1, 5):
+        got = ms.run(rounds, dl, L, dv)
+        want = ms_np.mean_shift(lab, L, var, rounds)
+        assert np.isnan(got[2]).all() and np.isnan(want[2]).all()
+        assert np.abs(got[:2] - want[:2]).max() < 1e-9, np.abs(got[:2] - want[:2]).max()
+        assert np.array_equal(got.view(np.uint64), ms.run(rounds, dl, L, dv).view(np.uint64))
