@@ -47,7 +47,8 @@ namespace {
 
 constexpr int kGroup = 4;          // trees walked interleaved by one lane (template GROUP: 1 and 2 for smaller forests)
 constexpr int kMaxRowsPerWave = 4; // label rows each wave owns in a tile (fewer for small launches)
-constexpr int kDefaultLdsBudget = 32700;   // node table + depth tile per workgroup
+constexpr int kDefaultLdsBudget = 32700;   // node table + depth tile per 256-thread workgroup (five per CU)
+constexpr int kDefaultLdsBudget512 = 54600;   // ... per 512-thread workgroup (three per CU)
 constexpr int kDefaultHalo = 32;   // depth pixels staged around a tile's centres
 constexpr int kMinLdsLevels = 6;   // top levels of every tree that stay in LDS when the depth tile competes for it
 constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
@@ -118,6 +119,7 @@ struct EvalArgs {
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
     int cpad;                  // classes rounded up to a multiple of 4
     int filter_class;
+    int check_empty;       // look at a tile's centre depths before staging it (throughput shape)
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
     int fill_untouched;    // fused pre-fill: write 65535 to every label pixel that is not evaluated
     float s;
@@ -204,7 +206,9 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
 // FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
 // a.rows_per_wave rows (latency shape for small launches such as one live frame).
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
+// second launch bound = waves per SIMD the register allocation must allow: three 512-thread workgroups per CU are six
+// waves per SIMD (80 VGPRs; the 4-wide walk needs 86 without the bound and spills two dwords with it)
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint4 *lds_nodes = reinterpret_cast<uint4 *>(lds_raw);
@@ -272,8 +276,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_forest(const EvalArgs a)
 
         // ---- empty tile?  (live frames are mostly background.)  Every wave looks at the centre depths of its
         // own rows straight from global memory; a tile without a single pixel to evaluate is not staged.
-        // Throughput shape only: with one row per wave the extra round trip costs more than it saves ----
-        if (FULLROWS && tw > 0) {
+        // Throughput shape only (a.check_empty): for a single small frame the extra round trip costs more than it saves ----
+        if (a.check_empty && tw > 0) {
             bool mine = false;
             for (int sub = 0; sub < rows_per_wave; ++sub) {
                 const uint32_t trow = (uint32_t)sub * kWaves + wave;
@@ -754,9 +758,10 @@ int env_int(const char *name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
-int lds_budget()
+int lds_budget(int block)
 {
-    int b = g_lds_budget > 0 ? g_lds_budget : env_int("RDF_LDS_BUDGET", kDefaultLdsBudget);
+    // per workgroup: five 256-thread or three 512-thread workgroups share a CU's 160 KB
+    int b = g_lds_budget > 0 ? g_lds_budget : env_int("RDF_LDS_BUDGET", block == 512 ? kDefaultLdsBudget512 : kDefaultLdsBudget);
     if (b > 160 * 1024) b = 160 * 1024;
     if (b < 0) b = 0;
     return b;
@@ -1009,15 +1014,23 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         a.cpad = (n_classes + 3) & ~3;
     }
 
-    int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
     a.tiles_x = ((uint32_t)a.Wl + 63u) / 64u;
-    if (block != 256 && block != 512 && block != 1024) block = 256;   // measured best on MI355X (profiles/)
-    // rows per wave: 4 amortises the tile staging; small launches (a single live frame) take fewer rows
-    // per wave so that every CU still gets several waves
+    // Throughput shape: the launch fills the chip with four-row waves.  Small launches (a single live frame) take fewer
+    // rows per wave so that every CU still gets several waves.
+    const long long waves_wanted = 24ll * di.cus;
+    const bool big = (long long)n_img * a.tiles_x * ((a.Hl + kMaxRowsPerWave - 1) / kMaxRowsPerWave) >= waves_wanted;
+    a.check_empty = big ? 1 : 0;
+    // Workgroup size.  Big unfiltered launches: 512 threads, three workgroups per CU = 24 waves with a 48-pixel halo
+    // (54 KB of LDS each) instead of five 256-thread workgroups = 20 waves with 32 pixels: 4.77 vs 5.14 ms on the bench
+    // batch, 11.98 vs 12.60 ms on config 5's shard (profiles/r02_sweep_512.txt).  Filtered launches keep 256 threads
+    // (the pixel-list kernels exist for that size only: 1.45 vs 2.10 ms), small launches too.
+    const bool filtered_compact = !stats && filter_class != -1 && g_compaction != 0;
+    int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
+    if (block != 256 && block != 512 && block != 1024) block = (big && !filtered_compact && !stats) ? 512 : 256;
     int rpw = g_rows_per_wave > 0 ? g_rows_per_wave : env_int("RDF_ROWS_PER_WAVE", 0);
     if (rpw < 1 || rpw > kMaxRowsPerWave) {
         rpw = kMaxRowsPerWave;
-        const long long waves_wanted = 24ll * di.cus;
+        if (big && block == 512) rpw = 2;      // 8 waves x 2 rows: the 64 x 16 tile of four waves x 4 rows
         while (rpw > 1 && (long long)n_img * a.tiles_x * ((a.Hl + rpw - 1) / rpw) < waves_wanted) rpw >>= 1;
     }
     a.rows_per_wave = rpw;
@@ -1028,20 +1041,24 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     a.n_tiles = (uint32_t)n_tiles;
 
     // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B][pixel list] ----
-    const long long budget = lds_budget();
+    const long long budget = lds_budget(block);
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
     const bool compact_launch = block == 256 && !stats && filter_class != -1 && g_compaction != 0;
-    // forests of eight and more trees trade one more LDS level for eight more pixels of halo (config 5's shape, T8/D22:
-    // 6 levels + 32 px 12.90 ms, 5 levels + 40 px 12.68 ms; four trees: 7 + 32 5.17 ms, 6 + 40 5.61 ms)
+    // Halo and the levels that must stay in LDS, by measurement (profiles/r02_sweep_*.txt).  256-thread workgroups (32.7 KB):
+    // four trees 7 levels + 32 px (5.17 ms; 8 + 24: 5.26, 6 + 40: 5.61), eight trees 5 levels + 40 px (config 5's shape:
+    // 12.68 ms; 6 + 32: 12.90).  512-thread workgroups (54.6 KB): 56 px with 7 levels (4.74 ms; 8 + 48: 4.76) or, for eight
+    // trees, 5 levels (11.45 ms; 6 + 48: 11.66).  With labels_reduce > 1 the halo shrinks until the tile fits.
     const bool many_trees = n_trees >= 8;
-    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", many_trees ? kDefaultHalo + 8 : kDefaultHalo);
+    // (labels_reduce 2, 64 frames, 512 threads: 6 levels + 32 px 0.81 ms, 7 + 40 0.89 ms -- a tile spans r times the pixels)
+    const int halo_default = block == 512 ? (r > 1 ? 32 : 56) : (many_trees ? kDefaultHalo + 8 : kDefaultHalo);
+    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", halo_default);
     long long tile_bytes = 0;
     // The staged tile may take half the budget.  With labels_reduce > 1 a tile spans r times the pixels per label, so
     // the halo shrinks (by twos) until the tile fits -- a narrow tile still beats none: 64 frames at r = 2 take 1.08 ms
     // with an 8-pixel halo against 1.49 ms with every probe going to global memory; only when not even the bare
     // centres fit is the tile dropped.
     // (Throughput shape only: for a single small frame staging a narrow tile cost more than it saved, 91 vs 87 us.)
-    const int h_min = rpw == kMaxRowsPerWave ? 0 : halo;
+    const int h_min = big ? 0 : halo;
     // pixel list: one uint16 per tile pixel, then one uint32 per tile row
     const long long list_bytes = compact_launch ? (((long long)block * rpw * 2 + (long long)tile_rows * 4) + 15) & ~15ll : 0;
     // levels of the forest the caller pinned into LDS (rdf_set_lds_levels): the tile then gets all that is left of the
@@ -1052,7 +1069,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // otherwise the tile may take what kMinLdsLevels levels of the forest leave: level for level, a level moved from LDS
     // to L1-resident global records costs less than the far probes a wider halo saves (measured: T4, 8 levels + 24 px
     // 5.26 ms, 7 levels + 32 px 5.17 ms, 6 levels + 40 px 5.6 ms on the bench batch)
-    const int k_min = many_trees ? kMinLdsLevels - 1 : kMinLdsLevels;
+    const int k_min = many_trees ? kMinLdsLevels - 1 : (block == 512 && r == 1 ? kMinLdsLevels + 1 : kMinLdsLevels);
     const int k_floor = k_forced >= 0 ? k_forced : (max_depth < k_min ? max_depth : k_min);
     const long long tile_budget = budget - 32 - list_bytes - (k_floor > 0 ? (long long)n_trees * (1ll << k_floor) * 16 : 0);
     // 16-byte staging needs every row start 16-byte aligned in the image and in LDS

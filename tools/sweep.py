@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--no-compaction", action="store_true")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=848)
-    ap.add_argument("combos", nargs="*", default=["1024:81920", "512:81920", "512:32768", "256:32768", "256:16384"])
+    ap.add_argument("combos", nargs="*", default=["0:0", "256:32700", "512:54600"], help="0:0 = every default")
     a = ap.parse_args()
     import torch
     rdf = importlib.import_module("3d-beats_amd")
@@ -57,7 +57,7 @@ def main():
     for r in range(a.rounds + 1):
         for c in combos:
             lib.rdf_set_block_threads(c[0])
-            lib.rdf_set_lds_budget_bytes(c[1] if c[1] else 1)
+            lib.rdf_set_lds_budget_bytes(c[1])      # 0 = the library's default for the workgroup size
             lib.rdf_set_rows_per_wave(c[2] if len(c) > 2 else 0)
             lib.rdf_set_halo(c[3] if len(c) > 3 else -1)
             lib.rdf_set_lds_levels(c[4] if len(c) > 4 else -1)
