@@ -526,6 +526,105 @@ def test_cu_masked_stream_gives_the_same_labels(rdf, evs, oracle, gpu_runtime):
         assert lib.rdf_stream_destroy(h) == 0
 
 
+def test_cu_masked_stream_sizes_the_grid_on_the_reference_layout_path_too(rdf, evs, oracle, gpu_runtime):
+    """The unpacked entry point on a CU-masked stream: the persistent grid must be sized from the stream's CUs (round 1
+    passed the device's CU count on this one path) and the labels are the oracle's."""
+    import ctypes
+    import torch
+    lib = gpu_runtime.lib
+    h = ctypes.c_void_p()
+    assert lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), 64) == 0
+    try:
+        forest_np = rdf.synth.forest(4, 11, 4, "trained", first_tree=35)
+        depth = rdf.synth.mixed_batch(8, first_idx=4400, h=240, w=424)
+        want = np.full(depth.shape, 65535, np.uint16)
+        oracle.eval_forest(depth, forest_np, want)
+        forest = rdf.DecisionForest.from_numpy(forest_np)
+        d_dev = rdf.to_device(depth)
+        out = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.ExternalStream(h.value)):
+            evs["direct"].get_labels_forest(forest, d_dev, out)
+            got = out.get()
+        assert np.array_equal(got, want)
+    finally:
+        torch.cuda.synchronize()
+        assert lib.rdf_stream_destroy(h) == 0
+
+
+def test_destroyed_streams_give_their_queue_slots_back(rdf, evs, oracle, gpu_runtime):
+    """A device has 256 tile-queue slots for streams; rdf_stream_destroy returns a stream's slot, so a program that
+    creates and destroys more streams than that keeps the dynamic queue (round 1 leaked the slot and fell back to
+    static tiles for good after 256 streams)."""
+    import ctypes
+    import torch
+    lib = gpu_runtime.lib
+    forest_np = rdf.synth.forest(4, 9, 4, "trained", first_tree=36)
+    depth = rdf.synth.mixed_batch(2, first_idx=4500, h=120, w=200)
+    want = np.full(depth.shape, 65535, np.uint16)
+    oracle.eval_forest(depth, forest_np, want)
+    forest = rdf.DecisionForest.from_numpy(forest_np)
+    d_dev = rdf.to_device(depth)
+    out = rdf.DeviceArray(depth.shape, np.uint16)
+    used, graph = ctypes.c_int(), ctypes.c_int()
+    assert lib.rdf_debug_sched_slots(ctypes.byref(used), ctypes.byref(graph)) == 0
+    before = used.value
+    for i in range(300):
+        h = ctypes.c_void_p()
+        assert lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), 32) == 0
+        with torch.cuda.stream(torch.cuda.ExternalStream(h.value)):
+            out.fill(65535)
+            evs["packed"].get_labels_forest(forest, d_dev, out)
+        assert lib.rdf_stream_destroy(h) == 0            # waits for the stream's work
+        if i % 97 == 0:
+            assert np.array_equal(out.get(), want), i
+    assert lib.rdf_debug_sched_slots(ctypes.byref(used), ctypes.byref(graph)) == 0
+    assert used.value <= before + 1, (before, used.value)
+    assert np.array_equal(out.get(), want)
+
+
+def test_captured_launch_has_its_own_queue_slot_and_replays_next_to_direct_launches(rdf, evs, oracle, gpu_runtime):
+    """A forest launch recorded into a hipGraph gets a tile-queue slot of its own: the graph is replayed on ANOTHER stream
+    while direct launches run on the stream it was captured on (round 1 keyed both by the capture stream's handle: two
+    concurrent launches then stole each other's tiles).  Every replay and every direct launch gives the oracle's labels."""
+    import ctypes
+    import torch
+    lib = gpu_runtime.lib
+    synth = rdf.synth
+    fa, fb = synth.forest(4, 11, 4, "trained", 3), synth.forest(4, 10, 4, "full", 7)
+    da, db = synth.frames(["live", "dense", "live"], 820, 240, 424), synth.frames(["dense", "live"], 830, 200, 300)
+    wa, wb = np.full(da.shape, 65535, np.uint16), np.full(db.shape, 65535, np.uint16)
+    oracle.eval_forest(da, fa, wa)
+    oracle.eval_forest(db, fb, wb)
+    Fa, Fb = rdf.DecisionForest.from_numpy(fa), rdf.DecisionForest.from_numpy(fb)
+    Da, Db = rdf.to_device(da), rdf.to_device(db)
+    La, Lb = rdf.DeviceArray(da.shape, np.uint16), rdf.DeviceArray(db.shape, np.uint16)
+    Fa.packed(1.0), Fb.packed(1.0)
+    ev = evs["packed"]
+    cap, other = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        La.fill(65535)
+        ev.get_labels_forest(Fa, Da, La)
+    cap.synchronize()
+    used, g0, g1 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.rdf_debug_sched_slots(ctypes.byref(used), ctypes.byref(g0))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        La.fill(65535)
+        ev.get_labels_forest(Fa, Da, La)
+    lib.rdf_debug_sched_slots(ctypes.byref(used), ctypes.byref(g1))
+    assert g1.value == g0.value + 1
+    for it in range(20):
+        with torch.cuda.stream(other):
+            graph.replay()                              # on a stream the graph was not captured on
+        with torch.cuda.stream(cap):
+            Lb.fill(65535)
+            ev.get_labels_forest(Fb, Db, Lb)            # direct launch on the capture stream, concurrently
+        torch.cuda.synchronize()
+        assert np.array_equal(La.get(), wa), it
+        assert np.array_equal(Lb.get(), wb), it
+
+
 @pytest.mark.parametrize("r,s", [(1, 1.0), (3, 0.5)])
 def test_three_layer_stack_matches_oracle(r, s, rdf, gpu_runtime, oracle):
     """A 3-layer stack (layer 1 filtered on a class of layer 0, layer 2 on a class of layer 1) with a conditions
