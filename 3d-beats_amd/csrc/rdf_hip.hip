@@ -873,12 +873,12 @@ template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP
 int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st);
 
 // Filtered launches (a layer that only looks at one class of an earlier layer) list the pixels to evaluate first and
-// deal them to the waves 64 at a time (COMPACT); these exist for the default workgroup size only.
+// deal them to the waves 64 at a time (COMPACT); these exist for 256- and 512-thread workgroups.
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
 int launch_group(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    if (BLOCK == 256 && !STATS && a.filter_class != -1 && g_compaction != 0)   // == compact_launch in eval_common, which sized the LDS for it
-        return launch_compact<256, PACKED, CMAX, false, FULLROWS, GROUP, true>(a, lds_bytes, cus, st);
+    if ((BLOCK == 256 || BLOCK == 512) && !STATS && a.filter_class != -1 && g_compaction != 0)   // == compact_launch in eval_common, which sized the LDS for it
+        return launch_compact<(BLOCK == 512 ? 512 : 256), PACKED, CMAX, false, FULLROWS, GROUP, true>(a, lds_bytes, cus, st);
     return launch_compact<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP, false>(a, lds_bytes, cus, st);
 }
 
@@ -1022,11 +1022,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     a.check_empty = big ? 1 : 0;
     // Workgroup size.  Big unfiltered launches: 512 threads, three workgroups per CU = 24 waves with a 48-pixel halo
     // (54 KB of LDS each) instead of five 256-thread workgroups = 20 waves with 32 pixels: 4.77 vs 5.14 ms on the bench
-    // batch, 11.98 vs 12.60 ms on config 5's shard (profiles/r02_sweep_512.txt).  Filtered launches keep 256 threads
-    // (the pixel-list kernels exist for that size only: 1.45 vs 2.10 ms), small launches too.
-    const bool filtered_compact = !stats && filter_class != -1 && g_compaction != 0;
+    // batch, 11.45 vs 12.60 ms on config 5's shard (profiles/r02_sweep_512.txt).  Small launches keep 256 threads.
     int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
-    if (block != 256 && block != 512 && block != 1024) block = (big && !filtered_compact && !stats) ? 512 : 256;
+    // (filtered launches at labels_reduce 1 gain nothing from 512 threads: 1.36 ms either way, 1.63 with this default's
+    // halo; at labels_reduce 2 they do: 0.46 vs 0.55 ms)
+    const bool filtered_r1 = filter_class != -1 && g_compaction != 0 && r == 1;
+    if (block != 256 && block != 512 && block != 1024) block = (big && !stats && !filtered_r1) ? 512 : 256;
     int rpw = g_rows_per_wave > 0 ? g_rows_per_wave : env_int("RDF_ROWS_PER_WAVE", 0);
     if (rpw < 1 || rpw > kMaxRowsPerWave) {
         rpw = kMaxRowsPerWave;
@@ -1043,7 +1044,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B][pixel list] ----
     const long long budget = lds_budget(block);
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
-    const bool compact_launch = block == 256 && !stats && filter_class != -1 && g_compaction != 0;
+    const bool compact_launch = (block == 256 || block == 512) && !stats && filter_class != -1 && g_compaction != 0;
     // Halo and the levels that must stay in LDS, by measurement (profiles/r02_sweep_*.txt).  256-thread workgroups (32.7 KB):
     // four trees 7 levels + 32 px (5.17 ms; 8 + 24: 5.26, 6 + 40: 5.61), eight trees 5 levels + 40 px (config 5's shape:
     // 12.68 ms; 6 + 32: 12.90).  512-thread workgroups (54.6 KB): 56 px with 7 levels (4.74 ms; 8 + 48: 4.76) or, for eight
