@@ -17,7 +17,11 @@
 //   * floor((u)/d) uses the shared-reciprocal divide verified exhaustively for inference
 //     (tools/verify_fastdiv.hip) with the IEEE divide for numerators outside the verified range.
 // Counts are integers, so they are exact whatever the order; the fp32 gain arithmetic follows the
-// reference expression by expression (built with -ffp-contract=off).
+// reference expression by expression (built with -ffp-contract=off).  Limit: the reference's kernels go through nvcc,
+// whose default (--fmad=true) contracts p + p_i*p_i and the weighted impurity sum into FMAs; a gain can differ from the
+// reference binary's in the last ulp and a strict `>` on a near-tie can then pick another proposal.  Trained trees are
+// bit-identical to oracle/train_numpy.py (the same unfused arithmetic), not provably to what the reference binary would
+// train.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

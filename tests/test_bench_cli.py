@@ -41,7 +41,7 @@ def test_single_gpu_line_has_roofline_and_legs(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gather", ["p2p", "rccl"])
+@pytest.mark.parametrize("gather", ["p2p", "rccl", "both"])
 def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
     env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -55,4 +55,5 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
     assert dd["rccl_ranks"] == 2 and len(dd["devices"]) == 2 and dd["kernel_only_ms"] > 0 and dd["value_kernel_only"] >= d["value"] * 0.5
     assert dd["distinct_devices"] == 1                      # both ranks share the test box's GPU; 8 on the driver's node
     assert all(m["gather_check"] == "ok" for m in dd["gather_modes"].values())
-    assert ("p2p" in d["config"]["gather"]) == (gather == "p2p")
+    assert ("p2p" in d["config"]["gather"]) == (gather in ("p2p", "both"))
+    assert len(dd["gather_modes"]) == (2 if gather == "both" else 1)
