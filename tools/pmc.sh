@@ -4,7 +4,7 @@
 # usage: tools/pmc.sh <out_dir_under_gpurun_out> [bench args...]
 set -u
 OUT=${1:-pmc}; shift || true
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 3 --warmup 1 --headline-only}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Individual, time-boxed PMC passes (TCP/TA counters crashed rocprofv3 when grouped; see profiles/).
-# usage: tools/pmc2.sh <out> "<bench args>" pass1:"C1 C2" pass2:"C3" ...
+# usage: tools/pmc2.sh <out> "<bench args, include --headline-only or --leg X: a full bench.py run profiles itself>" pass1:"C1 C2" pass2:"C3" ...
 set -u
 OUT=$1; ARGS=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
