@@ -625,6 +625,71 @@ def test_captured_launch_has_its_own_queue_slot_and_replays_next_to_direct_launc
         assert np.array_equal(Lb.get(), wb), it
 
 
+def test_three_layer_run_eager_and_captured_with_a_filter_that_never_matches(rdf, gpu_runtime, oracle):
+    """A three-layer stack at labels_reduce 2 on changing frames, eager and replayed from a captured graph, and with a
+    layer whose filter class no pixel has (layers 1 and 2 then come out all-65535): per-layer label images and composite
+    equal the oracle's chain."""
+    import torch
+    synth = rdf.synth
+    lib = gpu_runtime.lib
+    h, w, r = 240, 424, 2
+    forests = [synth.forest(4, 9, 4, "trained", 200), synth.forest(3, 10, 5, "trained", 210), synth.forest(4, 8, 3, "trained", 220)]
+    conditions = [[0, 1], [1, 4], [0, 2], [0, 3], [0, 4], [1, 9], [0, 5], [0, 6], [0, 7], [0, 8], [0, 9], [0, 10]]
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(forests[0])},
+                      {"model": rdf.DecisionForest.from_numpy(forests[1]), "filter_model": 0, "filter_model_class": 2},
+                      {"model": rdf.DecisionForest.from_numpy(forests[2]), "filter_model": 1, "filter_model_class": 2}],
+           "conditions": conditions, "label_colors": [[i, i, i, 255] for i in range(10)]}
+    try:
+        lf = rdf.LayeredDecisionForest(cfg, (h, w), r)
+        dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
+        frames = synth.frames(["live", "dense", "live"], 930, h, w)
+
+        def want_for(frame, cls1):
+            shape = (1, h // r, w // r)
+            l0, l1, l2, comp = (np.full(shape, 65535, np.uint16) for _ in range(4))
+            oracle.eval_forest(frame[None], forests[0], l0, r, None, None, 0.5)
+            oracle.eval_forest(frame[None], forests[1], l1, r, l0, cls1, 0.5)
+            oracle.eval_forest(frame[None], forests[2], l2, r, l1, 2, 0.5)
+            oracle.composite([l0[0], l1[0], l2[0]], np.array(conditions, np.int32), comp)
+            return l0[0], l1[0], l2[0], comp[0]
+
+        for i in range(3):
+            dbuf.cu().set(frames[i])
+            lbuf.cu().fill(7)
+            lf.run(dbuf, lbuf, 0.5)
+            l0, l1, l2, comp = want_for(frames[i], 2)
+            assert np.array_equal(lf.label_images[0].cu().get(), l0), i
+            assert np.array_equal(lf.label_images[1].cu().get(), l1), i
+            assert np.array_equal(lf.label_images[2].cu().get(), l2), i
+            assert np.array_equal(lbuf.cu().get(), comp), i
+            assert (l1 != 65535).sum() > 50
+        # captured as a graph on a side stream, replayed on changing frames
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            lf.run(dbuf, lbuf, 0.5)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            lf.run(dbuf, lbuf, 0.5)
+        for i in (1, 0, 2):
+            dbuf.cu().set(frames[i])
+            graph.replay()
+            torch.cuda.synchronize()
+            l0, l1, l2, comp = want_for(frames[i], 2)
+            assert np.array_equal(lbuf.cu().get(), comp) and np.array_equal(lf.label_images[2].cu().get(), l2), i
+        # a filter class that no pixel of layer 0 has: layers 1 and 2 must come out all-65535
+        cfg["layers"][1]["filter_model_class"] = 9
+        lf9 = rdf.LayeredDecisionForest(cfg, (h, w), r)
+        dbuf.cu().set(frames[1])
+        lf9.run(dbuf, lbuf, 0.5)
+        l0, l1, l2, comp = want_for(frames[1], 9)
+        assert (l1 == 65535).all() and (l2 == 65535).all()
+        assert np.array_equal(lf9.label_images[1].cu().get(), l1) and np.array_equal(lf9.label_images[2].cu().get(), l2)
+        assert np.array_equal(lbuf.cu().get(), comp)
+    finally:
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("r,s", [(1, 1.0), (3, 0.5)])
 def test_three_layer_stack_matches_oracle(r, s, rdf, gpu_runtime, oracle):
     """A 3-layer stack (layer 1 filtered on a class of layer 0, layer 2 on a class of layer 1) with a conditions
