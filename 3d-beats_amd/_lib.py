@@ -76,6 +76,7 @@ SIGNATURES = {
     "rdf_set_lds_levels": (None, [_c_int]),
     "rdf_set_stage_vec": (None, [_c_int]),
     "rdf_set_group": (None, [_c_int]),
+    "rdf_set_layers_one_launch": (None, [_c_int]),
     "rdf_set_rows_per_wave": (None, [_c_int]),
     "rdf_set_force_exact": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),

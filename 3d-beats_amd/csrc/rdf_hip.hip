@@ -205,11 +205,22 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
 
 // FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
 // a.rows_per_wave rows (latency shape for small launches such as one live frame).
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
+// NL > 1 ("layers in one launch", small launches of a layered stack): workgroup b evaluates forest b % NL of the kernel's
+// NL argument sets on the same frame -- NL independent forest evaluations that share ONE launch, hence one ramp and one
+// drain (a small launch costs one wave-row's dependent chain however little it evaluates), with a tile queue per role.
+template <int NL>
+struct EvalArgsN {
+    EvalArgs l[NL];
+};
+
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT, int NL = 1>
 // second launch bound = waves per SIMD the register allocation must allow: three 512-thread workgroups per CU are six
 // waves per SIMD (80 VGPRs; the 4-wide walk needs 86 without the bound and spills two dwords with it)
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgs a)
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgsN<NL> ka)
 {
+    const uint32_t role = NL > 1 ? blockIdx.x % NL : 0u;           // workgroup-uniform
+    const uint32_t block_id = NL > 1 ? blockIdx.x / NL : blockIdx.x, n_blocks = NL > 1 ? gridDim.x / NL : gridDim.x;
+    const EvalArgs &a = ka.l[role];
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint4 *lds_nodes = reinterpret_cast<uint4 *>(lds_raw);
     uint16_t *lds_tile = reinterpret_cast<uint16_t *>(lds_raw + a.lds_tile_off);
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
     unsigned long long st_px = 0, st_lv = 0, st_lf = 0;
     const char *depth_b = reinterpret_cast<const char *>(a.depth);
     const int tw = a.tw, th = a.th, twp = a.twp;
-    uint32_t static_tile = blockIdx.x;
+    uint32_t static_tile = block_id;
 
     for (uint32_t it = 0;; ++it) {
         // ---- take the next tile: 64 label columns x tile_rows label rows of one image ----
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
         } else {
             __syncthreads();
             tile = static_tile;
-            static_tile += gridDim.x;
+            static_tile += n_blocks;
         }
         if (tile >= a.n_tiles) break;
         const uint32_t tiles_per_img = a.tiles_x * a.tiles_y;
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
     // workgroup has made its final, failing pull before it gets here) ----
     if (a.sched && tid == 0) {
         const unsigned int done = atomicAdd(a.sched + 1, 1u);
-        if (done == gridDim.x - 1u) {
+        if (done == n_blocks - 1u) {
             atomicExch(a.sched + 0, 0u);
             atomicExch(a.sched + 1, 0u);
         }
@@ -670,13 +681,44 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
 // mirrored in x (`flip_w` = label row width, 0 = as is; the app flips the left hand's labels back) and the label's
 // colour goes to an RGBA image at the same place (make_rgba_from_labels, points_ops.cu:258-281: labels 0, 65535 and
 // > num_colors leave the texel alone).
+// `spec.n` > 0: the layers were evaluated UNFILTERED in one launch (layered_run on a small launch); this kernel then
+// applies each layer's filter first -- layer i keeps its label only where the (already filtered) label of layer
+// spec.fl[i] equals spec.fc[i], else it becomes 65535, exactly what the filtered evaluation leaves behind its fill
+// (tree_eval.cu:81-85, decision_tree.py:237-240) -- and stores what changed.
+constexpr int kMaxSpecLayers = 4;
+struct SpecFilters {
+    int n;
+    int fl[kMaxSpecLayers], fc[kMaxSpecLayers];
+};
+
 __global__ __launch_bounds__(256) void k_composite(const uint16_t *const *imgs, int n_images, uint32_t n_px,
                                                    const int2 *cond, int n_cond, uint16_t *out, int32_t *bad,
                                                    int fill_untouched, uint32_t flip_w, const uint32_t *colors,
-                                                   int num_colors, uint32_t *rgba)
+                                                   int num_colors, uint32_t *rgba, const SpecFilters spec)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_px) return;
+    uint32_t lab[kMaxSpecLayers];
+    if (spec.n > 0) {
+#pragma unroll
+        for (int i = 0; i < kMaxSpecLayers; ++i) {
+            lab[i] = kNoPixel;
+            if (i < spec.n) {
+                uint32_t l = imgs[i][p];
+                if (spec.fl[i] >= 0) {
+                    uint32_t f = kNoPixel;
+#pragma unroll
+                    for (int j = 0; j < kMaxSpecLayers; ++j)
+                        if (j < i && j == spec.fl[i]) f = lab[j];
+                    if ((int)f != spec.fc[i] && l != kNoPixel) {
+                        l = kNoPixel;
+                        const_cast<uint16_t *>(imgs[i])[p] = (uint16_t)kNoPixel;
+                    }
+                }
+                lab[i] = l;
+            }
+        }
+    }
     uint32_t q = p;
     if (flip_w) {
         const uint32_t y = p / flip_w, x = p - y * flip_w;
@@ -685,7 +727,15 @@ __global__ __launch_bounds__(256) void k_composite(const uint16_t *const *imgs, 
     long long off = 0;
     bool invalid = true;   // fell off the last image (tree_eval.cu:246-247)
     for (int i = 0; i < n_images; ++i) {
-        const uint32_t l = imgs[i][p];
+        uint32_t l;
+        if (spec.n > 0) {
+            l = kNoPixel;
+#pragma unroll
+            for (int j = 0; j < kMaxSpecLayers; ++j)
+                if (j == i) l = lab[j];
+        } else {
+            l = imgs[i][p];
+        }
         if (l == 0u || l == kNoPixel) { invalid = false; break; }   // :235 -- pixel keeps its pre-fill
         const long long e = off + (long long)l - 1;
         if (e < 0 || e >= n_cond) break;
@@ -788,10 +838,11 @@ int device_info(DeviceInfo *out)
 // ---- scheduler slots: one per (device, stream) that has launched; beyond kSchedSlots distinct
 // streams the kernel falls back to static round-robin chunks (sched == nullptr) ----
 std::mutex g_sched_mu;
-std::map<std::pair<int, void *>, int> g_sched_slot;
+std::map<std::tuple<int, void *, int>, int> g_sched_slot;   // (device, stream, role of a multi-forest launch) -> slot
 std::map<int, unsigned int *> g_sched_base;     // device -> address of g_sched on that device
 int g_compaction = -1;                          // -1: filtered launches compact their pixels; 0: never
 int g_group = 0;                                // 0: trees per lane chosen by forest size; 1..4: forced (rdf_set_group)
+int g_layers_one_launch = -1;                   // -1/1: small packed layered runs evaluate their layers in one launch; 0: never
 int g_sched_mode = -1;                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic, 2 one tile per workgroup
 
 int sched_mode()
@@ -808,7 +859,7 @@ std::map<int, std::vector<int>> g_sched_free;   // device -> stream slots given 
 std::map<int, int> g_sched_next;                // device -> stream slots handed out so far
 std::map<int, int> g_graph_next;                // device -> graph slots handed out so far
 
-unsigned int *sched_slot(void *stream)
+unsigned int *sched_slot(void *stream, int role = 0)
 {
     if (sched_mode() != 1) return nullptr;
     int dev = 0;
@@ -827,7 +878,7 @@ unsigned int *sched_slot(void *stream)
         if (n >= kGraphSlots) return nullptr;   // static tiles: slower on uneven batches, never wrong
         return bit->second + 2 * (kSchedSlots + n++);
     }
-    const auto key = std::make_pair(dev, stream);
+    const auto key = std::make_tuple(dev, stream, role);
     auto it = g_sched_slot.find(key);
     if (it == g_sched_slot.end()) {
         int slot = -1;
@@ -913,7 +964,43 @@ int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
     long long grid = sched_mode() == 2 ? (long long)a.n_tiles : (long long)cus * per_cu;
     if (grid > (long long)a.n_tiles) grid = a.n_tiles;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, a);
+    EvalArgsN<1> ka;
+    ka.l[0] = a;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, ka);
+    return (int)hipGetLastError();
+}
+
+// NL forests (the layers of a small layered run) in one launch: 256 threads, runtime rows, four trees per lane, no
+// pixel list -- the one geometry every small packed launch can take.
+template <int CMAX, int NL>
+int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st)
+{
+    auto kern = k_eval_forest<256, true, CMAX, false, false, kGroup, false, NL>;
+    const void *kp = reinterpret_cast<const void *>(kern);
+    int per_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    const auto key = std::make_tuple(dev, kp, lds_bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        auto it = g_occ_cache.find(key);
+        if (it != g_occ_cache.end()) per_cu = it->second;
+    }
+    if (per_cu == 0) {
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds_bytes) != hipSuccess || n < 1) n = 1;
+        per_cu = n;
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        g_occ_cache[key] = per_cu;
+    }
+    // every role gets the same number of persistent workgroups (all roles have the same tiles: same frame, same reduce)
+    long long per_role = (long long)cus * per_cu / NL;
+    if (per_role > (long long)ka.l[0].n_tiles) per_role = ka.l[0].n_tiles;
+    if (per_role < 1) per_role = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_role * NL)), dim3(256), lds_bytes, st, ka);
     return (int)hipGetLastError();
 }
 
@@ -979,13 +1066,24 @@ int g_stage_vec = -1;
 int g_rows_per_wave = 0;
 int g_force_exact = 0;
 
+// What eval_common works out before it launches: the kernel arguments (without a queue slot), the dynamic LDS and the
+// geometry.  layered_run asks for the plan only (plan_only) to put several layers into one launch.
+struct Plan {
+    EvalArgs a;
+    int lds_bytes = 0, block = 0;
+    bool big = false, empty = false;
+};
+
 int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
                 const float *forest, int n_trees, int max_depth, int n_classes, const uint16_t *filter,
                 int filter_class, uint16_t *labels_out, int r, float s, int keep_if_no_leaf,
-                unsigned long long *stats, void *stream, int fill_untouched = 0)
+                unsigned long long *stats, void *stream, int fill_untouched = 0, Plan *plan_only = nullptr)
 {
     int rc = check_common(depth, n_img, dim_x, dim_y, forest, n_trees, max_depth, n_classes, labels_out, r);
-    if (rc == 1) return RDF_OK;
+    if (rc == 1) {
+        if (plan_only) plan_only->empty = true;
+        return RDF_OK;
+    }
     if (rc != 0) return rc;
     if (filter_class != -1 && !filter) return RDF_ERR_NULL_PTR;
 
@@ -1103,6 +1201,13 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     a.lds_mail_off = (uint32_t)(node_bytes + 16 + tile_bytes);
     a.lds_list_off = (uint32_t)(node_bytes + 32 + tile_bytes);
     const int lds_bytes = (int)(node_bytes + tile_bytes + 32 + list_bytes);
+    if (plan_only) {
+        plan_only->a = a;
+        plan_only->lds_bytes = lds_bytes;
+        plan_only->block = block;
+        plan_only->big = big;
+        return RDF_OK;
+    }
 
     a.sched = sched_slot(stream);
 
@@ -1199,7 +1304,7 @@ int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, 
     const unsigned blocks = (unsigned)((n_px + 255) / 256);
     hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        label_images, n_images, (uint32_t)n_px, reinterpret_cast<const int2 *>(cond), n_cond, out,
-                       bad_count, 0, 0u, nullptr, 0, nullptr);
+                       bad_count, 0, 0u, nullptr, 0, nullptr, SpecFilters{});
     return (int)hipGetLastError();
 }
 
@@ -1215,11 +1320,68 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
                          !layer_labels || !layer_labels_dev_table))
         return RDF_ERR_NULL_PTR;
     if (!composite_out) return RDF_ERR_NULL_PTR;
-    for (int i = 0; i < n_layers; ++i) {
-        const int fl = filter_layer[i];
+    for (int i = 0; i < n_layers; ++i)
         // a layer may only filter on an EARLIER layer here: the fills of LayeredDecisionForest.run are folded into the
         // kernels, so a later layer's buffer still holds the previous frame (the host wrapper takes the step-by-step path)
-        if (fl >= i) return RDF_ERR_BAD_ARG;
+        if (filter_layer[i] >= i) return RDF_ERR_BAD_ARG;
+
+    // Small launches (one frame) cost one wave-row's dependent chain (~40 us) each, however few pixels they evaluate, and
+    // layer i+1 waits for layer i only because of its filter.  So the layers of a small packed stack are evaluated
+    // UNFILTERED in ONE launch (workgroup b takes layer b % n_layers: k_eval_forest<..., NL>) and the composite kernel
+    // applies the filters afterwards (SpecFilters): same label images, same composite, one ramp and drain instead of
+    // n_layers.  Two launches on two streams do not get there: a cross-queue event join costs more than it saves
+    // (DESIGN.md section 4).  Big launches keep the filtered evaluation, which does less work.
+    SpecFilters spec = {};
+    const int want_multi = g_layers_one_launch >= 0 ? g_layers_one_launch : env_int("RDF_LAYERS_ONE_LAUNCH", 1);
+    if (want_multi && (n_layers == 2 || n_layers == 3) && packed) {
+        Plan plans[3];
+        bool ok = true;
+        int cmax = 4, lds = 0;
+        for (int i = 0; i < n_layers && ok; ++i) {
+            ok = packed[i] != nullptr && max_depth[i] <= 27 && n_trees[i] > 0 && max_depth[i] > 0;
+            if (!ok) break;
+            const int rc = eval_common(depth, 1, dim_x, dim_y, packed[i], forests[i], n_trees[i], max_depth[i], n_classes[i],
+                                       nullptr, -1, layer_labels[i], labels_reduce, 1.0f, 0, nullptr, stream,
+                                       /*fill_untouched=*/1, &plans[i]);
+            if (rc != RDF_OK) return rc;
+            const Plan &pl = plans[i];
+            ok = !pl.empty && !pl.big && pl.block == 256 && pl.a.rows_per_wave < kMaxRowsPerWave &&
+                 pl.a.rows_per_wave == plans[0].a.rows_per_wave && pl.a.n_tiles == plans[0].a.n_tiles;
+            cmax = n_classes[i] > 8 ? 16 : (n_classes[i] > 4 && cmax < 8 ? 8 : cmax);
+            lds = pl.lds_bytes > lds ? pl.lds_bytes : lds;
+        }
+        if (ok) {
+            DeviceInfo di;
+            int rc = device_info(&di);
+            if (rc != 0) return rc;
+            hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+            const int cus = usable_cus(st, di.cus);
+            for (int i = 0; i < n_layers; ++i) {
+                plans[i].a.sched = sched_slot(stream, i);
+                spec.fl[i] = filter_layer[i];
+                spec.fc[i] = filter_layer[i] >= 0 ? filter_class[i] : -1;
+            }
+            // (all roles or none on the dynamic queue: a role without a slot would stride over tiles the others pull)
+            bool all_sched = true;
+            for (int i = 0; i < n_layers; ++i) all_sched = all_sched && plans[i].a.sched != nullptr;
+            if (!all_sched) for (int i = 0; i < n_layers; ++i) plans[i].a.sched = nullptr;
+            if (n_layers == 2) {
+                EvalArgsN<2> ka;
+                ka.l[0] = plans[0].a; ka.l[1] = plans[1].a;
+                rc = cmax == 4 ? launch_multi<4, 2>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 2>(ka, lds, cus, st)
+                                                                                  : launch_multi<16, 2>(ka, lds, cus, st);
+            } else {
+                EvalArgsN<3> ka;
+                ka.l[0] = plans[0].a; ka.l[1] = plans[1].a; ka.l[2] = plans[2].a;
+                rc = cmax == 4 ? launch_multi<4, 3>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 3>(ka, lds, cus, st)
+                                                                                  : launch_multi<16, 3>(ka, lds, cus, st);
+            }
+            if (rc != RDF_OK) return rc;
+            spec.n = n_layers;
+        }
+    }
+    for (int i = 0; i < n_layers && spec.n == 0; ++i) {
+        const int fl = filter_layer[i];
         const uint16_t *filt = fl >= 0 ? layer_labels[fl] : nullptr;
         const void *pk = packed ? packed[i] : nullptr;
         if (pk && max_depth[i] > 27) pk = nullptr;
@@ -1236,7 +1398,7 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
     hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        layer_labels_dev_table, n_layers, (uint32_t)n_px, reinterpret_cast<const int2 *>(cond), n_cond,
                        composite_out, bad_count, 1, flip_x ? (uint32_t)lw : 0u,
-                       reinterpret_cast<const uint32_t *>(colors_rgba), num_colors, reinterpret_cast<uint32_t *>(image_rgba));
+                       reinterpret_cast<const uint32_t *>(colors_rgba), num_colors, reinterpret_cast<uint32_t *>(image_rgba), spec);
     return (int)hipGetLastError();
 }
 
@@ -1300,6 +1462,7 @@ void rdf_set_scheduler(int mode) { g_sched_mode = mode; }
 void rdf_set_compaction(int mode) { g_compaction = mode; }
 void rdf_set_halo(int pixels) { g_halo = pixels; }
 void rdf_set_group(int trees) { g_group = trees; }
+void rdf_set_layers_one_launch(int on) { g_layers_one_launch = on; }
 void rdf_set_lds_levels(int levels) { g_lds_levels = levels; }
 void rdf_set_stage_vec(int on) { g_stage_vec = on; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
@@ -1337,8 +1500,8 @@ int rdf_stream_destroy(void *stream)
         for (auto it = g_stream_cus.begin(); it != g_stream_cus.end();)
             it = it->first.second == stream ? g_stream_cus.erase(it) : std::next(it);
         for (auto it = g_sched_slot.begin(); it != g_sched_slot.end();) {
-            if (it->first.second == stream) {
-                g_sched_free[it->first.first].push_back(it->second);
+            if (std::get<1>(it->first) == stream) {
+                g_sched_free[std::get<0>(it->first)].push_back(it->second);
                 it = g_sched_slot.erase(it);
             } else {
                 ++it;
@@ -1356,7 +1519,7 @@ int rdf_debug_sched_slots(int *stream_slots_in_use, int *graph_slots_used)
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_sched_mu);
     int used = 0;
-    for (const auto &kv : g_sched_slot) used += kv.first.first == dev;
+    for (const auto &kv : g_sched_slot) used += std::get<0>(kv.first) == dev;
     if (stream_slots_in_use) *stream_slots_in_use = used;
     if (graph_slots_used) *graph_slots_used = g_graph_next[dev];
     return RDF_OK;

@@ -519,8 +519,9 @@ def main():
         w3 = (time.perf_counter() - t3) / 100
         out["cfg3_layered_run"] = {"ms_per_frame_wall": round(w3 * 1e3, 4), "value": round(H * W / w3 / 1e6, 2),
                                    "unit": "Mpix/s", "what": "LayeredDecisionForest.run, 2 layers (second filtered on "
-                                   "class 3 of the first), labels_reduce 2, one live-like 848x480 frame: ONE C-ABI call, 2 "
-                                   "forest launches + composite (the reference's three fills are folded into them)"}
+                                   "class 3 of the first), labels_reduce 2, one live-like 848x480 frame: ONE C-ABI call, both "
+                                   "layers in one forest launch (unfiltered; the composite kernel applies the filter and "
+                                   "the reference's three fills are folded in)"}
 
         # ---- host-buffer variant: pinned H2D of the frames + kernel + D2H of the labels (never `value`) ----
         if a.pcie:

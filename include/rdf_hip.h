@@ -75,7 +75,10 @@ int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, 
  * followed by the composite.  Equivalent to: fill composite_out and every layer_labels[i] with
  * 65535; rdf_eval_forest[_packed] per layer in order; rdf_composite -- but the fills are fused
  * into the kernels (they store 65535 wherever they write nothing), so a 2-layer run is 3
- * launches instead of 6.  One image per call, as in the reference.
+ * launches instead of 6.  One image per call, as in the reference.  A launch too small to fill the chip (one frame) of a
+ * packed stack of two or three layers evaluates the layers unfiltered in ONE launch (workgroup b takes layer
+ * b % n_layers) and applies the filters in the composite kernel: same label images and composite, one ramp and drain
+ * instead of n_layers (rdf_set_layers_one_launch(0) turns it off).
  *   packed, forests, n_trees, max_depth, n_classes, filter_layer (-1 = none), filter_class,
  *   layer_labels are HOST arrays of length n_layers (pointers inside them are device pointers;
  *   packed may be NULL, or hold NULL entries, to evaluate from the reference-layout forest);
@@ -281,6 +284,8 @@ void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a 
 void rdf_set_lds_levels(int levels);     /* top levels of every tree pinned in LDS (the depth tile then gets the rest of
                                             the LDS budget instead of half of it); -1 = fill what the tile leaves */
 void rdf_set_group(int trees);           /* trees a lane walks interleaved: 1..4, 0 = by forest size (256-thread workgroups only) */
+void rdf_set_layers_one_launch(int on);  /* rdf_layered_run on a small launch evaluates the layers of a packed 2- or 3-layer
+                                            stack unfiltered in ONE launch and filters in the composite kernel: 1/-1 (default) on, 0 off */
 void rdf_set_stage_vec(int on);          /* tile staging with 16-byte loads where alignment allows: 1/-1 (default) on, 0 off */
 void rdf_set_force_exact(int on);        /* test knob: rdf_forest_pack flags every node for the IEEE-divide path */
 

@@ -625,10 +625,13 @@ def test_captured_launch_has_its_own_queue_slot_and_replays_next_to_direct_launc
         assert np.array_equal(Lb.get(), wb), it
 
 
-def test_three_layer_run_eager_and_captured_with_a_filter_that_never_matches(rdf, gpu_runtime, oracle):
-    """A three-layer stack at labels_reduce 2 on changing frames, eager and replayed from a captured graph, and with a
-    layer whose filter class no pixel has (layers 1 and 2 then come out all-65535): per-layer label images and composite
-    equal the oracle's chain."""
+@pytest.mark.parametrize("one_launch", [1, 0])
+def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, rdf, gpu_runtime, oracle):
+    """A single-frame run of a packed stack evaluates its layers unfiltered in ONE launch (workgroup b takes layer b % n) and
+    filters in the composite kernel (rdf_set_layers_one_launch, default on for small launches); with it off the layers run
+    one after the other, filtered.  Same per-layer label images and composite either way: the oracle's chain -- on
+    changing frames, replayed from a captured graph, and with a layer whose filter class no pixel has (layers 1 and 2
+    then come out all-65535)."""
     import torch
     synth = rdf.synth
     lib = gpu_runtime.lib
@@ -639,6 +642,7 @@ def test_three_layer_run_eager_and_captured_with_a_filter_that_never_matches(rdf
                       {"model": rdf.DecisionForest.from_numpy(forests[1]), "filter_model": 0, "filter_model_class": 2},
                       {"model": rdf.DecisionForest.from_numpy(forests[2]), "filter_model": 1, "filter_model_class": 2}],
            "conditions": conditions, "label_colors": [[i, i, i, 255] for i in range(10)]}
+    lib.rdf_set_layers_one_launch(one_launch)
     try:
         lf = rdf.LayeredDecisionForest(cfg, (h, w), r)
         dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
@@ -688,6 +692,7 @@ def test_three_layer_run_eager_and_captured_with_a_filter_that_never_matches(rdf
         assert np.array_equal(lbuf.cu().get(), comp)
     finally:
         torch.cuda.synchronize()
+        lib.rdf_set_layers_one_launch(-1)
 
 
 @pytest.mark.parametrize("r,s", [(1, 1.0), (3, 0.5)])
