@@ -23,7 +23,8 @@ namespace {
 constexpr int kMsThreads = 1024;
 constexpr int kMsWaves = kMsThreads / 64;
 constexpr int kMsMaxClasses = 64;
-constexpr uint32_t kMsListCap = 36864;   // pixels of one class kept in LDS (147 456 B of the CU's 160 KB)
+constexpr uint32_t kMsListCap = 32768;   // pixels of one class kept in LDS (131 072 B of the CU's 160 KB)
+constexpr uint32_t kMsTabCap = 3072;     // dim_x + dim_y the per-round weight tables cover (24 576 B)
 constexpr int kMsSteps = 13;             // 16 waves x 13 steps x 512 pixels = 106 496 >= the app's 424 x 240 label map
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -51,7 +52,7 @@ __device__ __forceinline__ void block_sum3(double a, double b, double c, double 
 // per class), so no round needs anything from another workgroup.  The workgroup lists its class's pixels once, in pixel
 // order, in LDS (x | y << 16) and then iterates over the list: round 0 = centroid (:32-35), rounds >= 1 = kernel-weighted
 // shift (:36-47), means += sums[:2] / sums[2] after each (mean_shift.py:54-57).  A class with more than kMsListCap
-// pixels keeps its first kMsListCap in the list and rescans the label image from there on every round.  Every sum is
+// pixels is not listed: its rounds rescan the label image.  Every sum is
 // taken in a fixed order (thread-strided partial sums, shuffle tree, waves in order): bitwise reproducible.
 // An earlier version ran one launch per round over 64 workgroups with a cross-workgroup partial-sum hand-off at every
 // kernel boundary: 7 launches, 74 us for the app's 424x240 label map (profiles/r02_pipeline_kernel_stats_before.csv).
@@ -59,25 +60,27 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
                                                                  const float *variances, int num_rounds, double *means_out)
 {
     extern __shared__ uint32_t s_list[];
+    __shared__ double s_tab[kMsTabCap];      // round's weights by column, then by row (see the rounds below)
     __shared__ double s_red[kMsWaves][3];
     __shared__ uint32_t s_wave_cnt[kMsWaves];
-    __shared__ uint32_t s_rescan_from;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t want = blockIdx.x + 1u;
     const uint32_t n_px = (uint32_t)dim_x * (uint32_t)dim_y;
 
-    // ---- list this class's pixels in pixel order.  A wave takes kMsSteps x 512 consecutive pixels per batch, eight per
-    // lane and step (one 16-byte load; all of a batch's loads are in flight together and the labels stay in registers
-    // between counting and writing); list positions follow (batch, wave, step, lane, pixel) = pixel order, from ballots
-    // and popcounts, so the order does not depend on timing.  The first pixel that does not fit marks where the
-    // rounds rescan the image from. ----
+    // ---- list this class's pixels.  A wave takes kMsSteps x 512 consecutive pixels per batch, eight per lane and step
+    // (one 16-byte load; a step's eight match bits are one byte of a packed register); a lane's pixels go to consecutive
+    // list slots, the lanes of a wave, the waves and the batches follow each other in order -- positions come from a
+    // wave scan of the per-lane counts and the waves' totals, so the order does not depend on timing (the rounds' sums
+    // depend on the list order, and must be reproducible).  A class that does not fit the list (kMsListCap pixels) is
+    // not listed at all: its rounds rescan the label image. ----
     const bool vec_ok = (reinterpret_cast<uintptr_t>(labels) & 15u) == 0u;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    if (tid == 0) s_rescan_from = n_px;
     uint32_t n_class = 0;
     for (uint32_t batch0 = 0; batch0 < n_px; batch0 += kMsWaves * kMsSteps * 512u) {
         const uint32_t wbase = batch0 + (uint32_t)wave * (kMsSteps * 512u);
-        uint32_t m[kMsSteps];        // bit j: pixel j of this lane's eight is of the class
+        uint32_t mp[(kMsSteps + 3) / 4];      // byte k & 3 of word k >> 2: which of the lane's eight pixels of step k match
+#pragma unroll
+        for (int q = 0; q < (kMsSteps + 3) / 4; ++q) mp[q] = 0u;
+        uint32_t cnt = 0u;
 #pragma unroll
         for (int k = 0; k < kMsSteps; ++k) {
             const uint32_t p0 = wbase + ((uint32_t)k * 64u + (uint32_t)lane) * 8u;
@@ -92,40 +95,38 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
                 for (int j = 0; j < 8; ++j)
                     if (p0 + (uint32_t)j < n_px && labels[p0 + j] == want) bits |= 1u << j;
             }
-            m[k] = bits;
+            mp[k >> 2] |= bits << (8 * (k & 3));
+            cnt += (uint32_t)__builtin_popcount(bits);
         }
-        uint32_t before[kMsSteps];   // pixels of the class in this wave's batch before this lane's eight of step k
-        uint32_t wave_total = 0u;
+        // exclusive scan of the lanes' counts (fixed shuffle pattern) and the wave's total
+        uint32_t incl = cnt;
 #pragma unroll
-        for (int k = 0; k < kMsSteps; ++k) {
-            uint32_t pre = wave_total;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned long long bl = __ballot((m[k] >> j) & 1u);
-                wave_total += (uint32_t)__popcll(bl);
-                pre += (uint32_t)__popcll(bl & lt_mask);       // lower lanes' pixel j ...
-            }
-            // ... counted every lower lane's eight pixels bit by bit: exactly the pixels before this lane's first
-            before[k] = pre;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
         }
+        const uint32_t lane_off = incl - cnt, wave_total = __shfl(incl, 63);
         __syncthreads();             // the previous batch's s_wave_cnt has been read
         if (lane == 0) s_wave_cnt[wave] = wave_total;
         __syncthreads();
-        uint32_t pos = n_class, batch_total = 0u;
+        uint32_t at = n_class + lane_off, batch_total = 0u;
         for (int w = 0; w < kMsWaves; ++w) {
-            if (w < wave) pos += s_wave_cnt[w];
+            if (w < wave) at += s_wave_cnt[w];
             batch_total += s_wave_cnt[w];
         }
+        if (cnt != 0u && at < kMsListCap) {      // (a lane whose first slot is beyond the list writes nothing: the class overflows)
 #pragma unroll
-        for (int k = 0; k < kMsSteps; ++k) {
-            uint32_t at = pos + before[k];
-            const uint32_t p0 = wbase + ((uint32_t)k * 64u + (uint32_t)lane) * 8u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if ((m[k] >> j) & 1u) {
-                    const uint32_t p = p0 + (uint32_t)j;
-                    if (at < kMsListCap) s_list[at] = (p % (uint32_t)dim_x) | ((p / (uint32_t)dim_x) << 16);
-                    else if (at == kMsListCap) s_rescan_from = p;
+            for (int k = 0; k < kMsSteps; ++k) {
+                uint32_t mk = (mp[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                if (mk == 0u) continue;
+                const uint32_t p0 = wbase + ((uint32_t)k * 64u + (uint32_t)lane) * 8u;
+                const uint32_t y0 = p0 / (uint32_t)dim_x, x0 = p0 - y0 * (uint32_t)dim_x;   // one division per eight pixels
+                while (mk) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(mk);
+                    mk &= mk - 1u;
+                    uint32_t x = x0 + j, y = y0;
+                    while (x >= (uint32_t)dim_x) { x -= (uint32_t)dim_x; ++y; }              // (rows narrower than 8 wrap more than once)
+                    if (at < kMsListCap) s_list[at] = x | (y << 16);
                     ++at;
                 }
             }
@@ -133,29 +134,49 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
         n_class += batch_total;
     }
     __syncthreads();
-    const uint32_t n_list = min(n_class, kMsListCap), rescan_from = s_rescan_from;
+    const bool listed = n_class <= kMsListCap;
+    const uint32_t n_list = listed ? n_class : 0u, rescan_from = listed ? n_px : 0u;
 
     double mx = 0.0, my = 0.0;
     const float vf = variances ? variances[blockIdx.x] : 0.0f;
     const double v_2 = (double)(vf * vf);          // float product, as mean_shift.cu:42
+    // The kernel weight factorises: exp(-((x-mx)^2 + (y-my)^2) / 2v^2) = exp(-(x-mx)^2 / 2v^2) * exp(-(y-my)^2 / 2v^2).
+    // A round therefore needs dim_x + dim_y exponentials per class (one table entry per thread), not one per pixel, and a
+    // pixel's weight is the product of two table entries (a few ulp from the exponential of the sum; the reference's own
+    // sums differ more from run to run).  That took the app's 424x240 map from ~6 us to ~1 us per round.
+    const bool tables = (uint32_t)dim_x + (uint32_t)dim_y <= kMsTabCap && v_2 > 0.0;
     for (int round = 0; round < num_rounds; ++round) {
         double sx = 0.0, sy = 0.0, sw = 0.0;
-        auto term = [&](double x, double y) {
+        if (round > 0 && tables) {
+            __syncthreads();                 // the previous round's readers are done with the tables
+            for (uint32_t i = tid; i < (uint32_t)dim_x + (uint32_t)dim_y; i += kMsThreads) {
+                const double c = i < (uint32_t)dim_x ? (double)(int)i - mx : (double)(int)(i - (uint32_t)dim_x) - my;
+                s_tab[i] = exp(-(c * c) / (2 * v_2));
+            }
+            __syncthreads();
+        }
+        auto term = [&](uint32_t xi, uint32_t yi) {
+            const double x = (double)(int)xi, y = (double)(int)yi;
             if (round == 0) {
                 sx += x; sy += y; sw += 1.0;
             } else {
                 const double dx = x - mx, dy = y - my;
-                const double dist_sq = (dx * dx) + (dy * dy);
-                const double w = exp(-dist_sq / (2 * v_2));
+                double w;
+                if (tables) {
+                    w = s_tab[xi] * s_tab[(uint32_t)dim_x + yi];
+                } else {
+                    const double dist_sq = (dx * dx) + (dy * dy);
+                    w = exp(-dist_sq / (2 * v_2));
+                }
                 sx += dx * w; sy += dy * w; sw += w;
             }
         };
         for (uint32_t i = tid; i < n_list; i += kMsThreads) {
             const uint32_t e = s_list[i];
-            term((double)(int)(e & 0xFFFFu), (double)(int)(e >> 16));
+            term(e & 0xFFFFu, e >> 16);
         }
         for (uint32_t p = rescan_from + tid; p < n_px; p += kMsThreads)
-            if (labels[p] == want) term((double)(int)(p % (uint32_t)dim_x), (double)(int)(p / (uint32_t)dim_x));
+            if (labels[p] == want) term(p % (uint32_t)dim_x, p / (uint32_t)dim_x);
         double tot[3];
         block_sum3(sx, sy, sw, s_red, tot);
         mx = mx + tot[0] / tot[2];                 // 0/0 = NaN for a class without pixels, as in the reference

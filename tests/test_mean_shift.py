@@ -85,7 +85,7 @@ def test_fingertip_heights_match_restatement(rdf, gpu_runtime):
 
 @pytest.mark.gpu
 def test_mean_shift_class_bigger_than_the_lds_list(rdf, gpu_runtime):
-    """A class with more pixels than one workgroup lists in LDS (36 864): the rest is rescanned from the label image every
+    """A class with more pixels than one workgroup lists in LDS (32 768): the rest is rescanned from the label image every
     round -- same means (1e-9 px), still bitwise reproducible; a neighbouring small class is unaffected."""
     msmod = importlib.import_module("3d-beats_amd.cuda.mean_shift")
     ms = msmod.MeanShift()
@@ -97,7 +97,7 @@ def test_mean_shift_class_bigger_than_the_lds_list(rdf, gpu_runtime):
     lab[0, 0] = 0
     var = np.array([80.0, 9.0, 5.0], np.float32)
     dl, dv = rdf.to_device(lab[None]), rdf.to_device(var)
-    assert (lab == 1).sum() > 2 * 36864
+    assert (lab == 1).sum() > 2 * 32768
     for rounds in (1, 5):
         got = ms.run(rounds, dl, L, dv)
         want = ms_np.mean_shift(lab, L, var, rounds)
