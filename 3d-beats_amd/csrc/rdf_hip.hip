@@ -6,8 +6,9 @@
 //     that kGroup node fetches and 2*kGroup depth probes are in flight per lane (the reference
 //     uses one thread per (pixel,tree), shared-memory float atomics and two block barriers);
 //   * a wave is 64 consecutive label pixels of one row; a workgroup owns a 2-D tile (64 columns x
-//     4 rows per wave, rows of the waves interleaved) whose depth neighbourhood it stages in LDS;
-//     the label store is one 128-byte line;
+//     1..4 rows per wave, rows of the waves interleaved) whose depth neighbourhood it stages in LDS;
+//     the label store is one 128-byte line.  Launches that fill the chip: 512 threads, three
+//     workgroups per CU (24 waves), 56-pixel halo; small launches: 256 threads, one row per wave;
 //   * per-tree leaf PDFs are added in registers in tree order (canonical order, no atomics);
 //   * node records are 16 bytes {4 x 23-bit floor(s*u), floor(s*v), integer threshold, flags}, decoded with one convert per numerator:
 //     the top levels of every tree live in LDS, deeper levels are ONE 128-bit load each from the
@@ -20,7 +21,9 @@
 //   * the workgroup's depth tile plus a halo is staged in LDS (out-of-image cells = 65535), so
 //     most probes are LDS reads with no bounds check; far probes go to global memory;
 //   * tiles are handed to persistent workgroups by a device-side queue (one atomic per tile), so
-//     empty (background) tiles cost almost nothing and frames of unequal cost balance out.
+//     empty (background) tiles cost almost nothing and frames of unequal cost balance out;
+//   * the layers of a small layered run share ONE launch (workgroup b walks layer b % NL, unfiltered;
+//     the composite kernel applies the filters): one ramp and drain instead of one per layer.
 //
 // Bit-exactness: the reference computes floor((s*u)/d) with one fp32 multiply, one IEEE-correct
 // fp32 divide and __float2int_rd.  The fast path here (integer numerator, shared refined
