@@ -695,6 +695,82 @@ def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, rdf, gpu_r
         lib.rdf_set_layers_one_launch(-1)
 
 
+def test_layered_fuzz_against_oracle(rdf, gpu_runtime, oracle):
+    """Seeded fuzz over layered stacks: 2-3 layers of random forests (1-9 trees, depth 1-11, 1-18 classes), random
+    filter wiring (on any earlier layer or none), reduce, scale, frame size and conditions table; LayeredDecisionForest.run
+    through all three routes -- layers in one launch, filtered launches one after the other, and the reference's
+    step-by-step sequence -- against the oracle's chain, per-layer label images and composite."""
+    rounds = int(os.environ.get("RDF_LAYERED_FUZZ_ROUNDS", "40"))
+    rng = np.random.default_rng(int(os.environ.get("RDF_FUZZ_SEED", "20211003")) + 17)
+    lib = gpu_runtime.lib
+    try:
+        for it in range(rounds):
+            n_layers = int(rng.integers(2, 4))
+            h, w = int(rng.integers(8, 140)), int(rng.integers(8, 260))
+            if rng.random() < 0.4:
+                w = max(8, w & ~7)
+            r = int(rng.choice([1, 1, 2, 3]))
+            if h // r == 0 or w // r == 0:
+                continue
+            s = float(rng.choice([1.0, 0.5, 1.5]))
+            forests, layers, n_classes = [], [], []
+            for i in range(n_layers):
+                T, D, C = int(rng.integers(1, 10)), int(rng.integers(1, 12)), int(rng.integers(1, 19))
+                f = rdf.synth.forest(T, D, C, str(rng.choice(["full", "trained"])), first_tree=1000 + 10 * it + i)
+                forests.append(f)
+                n_classes.append(C)
+                l = {"model": rdf.DecisionForest.from_numpy(f)}
+                if i > 0 and rng.random() < 0.8:
+                    l["filter_model"] = int(rng.integers(0, i))
+                    l["filter_model_class"] = int(rng.integers(0, n_classes[l["filter_model"]] + 1))
+                layers.append(l)
+            # a conditions table that terminates on every path: layer i's classes either name a composite id or go on
+            cond, n_ids = [], 0
+            offs = [0]
+            for i in range(n_layers):
+                for c in range(1, n_classes[i] + 1):
+                    if i + 1 < n_layers and rng.random() < 0.4:
+                        cond.append([1, -1])          # patched below with the next layer's offset
+                    else:
+                        n_ids += 1
+                        cond.append([0, n_ids])
+                offs.append(len(cond))
+            row = 0
+            for i in range(n_layers):
+                for c in range(n_classes[i]):
+                    if cond[row][0] == 1:
+                        cond[row][1] = offs[i + 1]
+                    row += 1
+            if n_ids == 0:
+                cond[0] = [0, 1]
+                n_ids = 1
+            cfg = {"layers": layers, "conditions": cond, "label_colors": [[i % 256, 0, 0, 255] for i in range(n_ids)]}
+            kind = str(rng.choice(["dense", "live"]))
+            frame = rdf.synth.frames([kind], 7000 + it, h, w)[0]
+            frame[rng.random(frame.shape) < 0.03] = 0
+            shape = (1, h // r, w // r)
+            want = [np.full(shape, 65535, np.uint16) for _ in range(n_layers)]
+            for i in range(n_layers):
+                fm = layers[i].get("filter_model")
+                oracle.eval_forest(frame[None], forests[i], want[i], r, want[fm] if fm is not None else None,
+                                   layers[i].get("filter_model_class"), s)
+            comp = np.full(shape, 65535, np.uint16)
+            oracle.composite([x[0] for x in want], np.array(cond, np.int32), comp)
+            dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
+            dbuf.cu().set(frame)
+            for route in ("one launch", "filtered launches", "step by step"):
+                lib.rdf_set_layers_one_launch(0 if route == "filtered launches" else -1)
+                lf = rdf.LayeredDecisionForest(cfg, (h, w), r, fused=route != "step by step")
+                lbuf.cu().fill(3)
+                lf.run(dbuf, lbuf, s)
+                for i in range(n_layers):
+                    got = lf.label_images[i].cu().get()
+                    assert np.array_equal(got, want[i][0]), f"iteration {it}, {route}, layer {i}: {(got != want[i][0]).sum()} pixels"
+                assert np.array_equal(lbuf.cu().get(), comp[0]), f"iteration {it}, {route}: composite"
+    finally:
+        lib.rdf_set_layers_one_launch(-1)
+
+
 @pytest.mark.parametrize("r,s", [(1, 1.0), (3, 0.5)])
 def test_three_layer_stack_matches_oracle(r, s, rdf, gpu_runtime, oracle):
     """A 3-layer stack (layer 1 filtered on a class of layer 0, layer 2 on a class of layer 1) with a conditions
