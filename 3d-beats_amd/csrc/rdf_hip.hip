@@ -55,15 +55,26 @@ constexpr int kDefaultLdsBudget512 = 54600;   // ... per 512-thread workgroup (t
 constexpr int kDefaultHalo = 32;   // depth pixels staged around a tile's centres
 constexpr int kMinLdsLevels = 6;   // top levels of every tree that stay in LDS when the depth tile competes for it
 constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
-constexpr int kSchedSlots = 256;        // one per (device, stream) that launches directly
-constexpr int kGraphSlots = 768;        // one per launch recorded into a hipGraph (stream capture)
+constexpr int kSchedSlots = 128;        // one per (device, stream) that launches directly
+constexpr int kGraphSlots = 384;        // one per launch recorded into a hipGraph (stream capture)
 
 // Dynamic tile queue state: {next tile, workgroups finished}.  One slot per (device, stream) that launches directly
 // (launches on one stream run in order, so they never meet in a slot) and a slot of its own for every launch recorded
 // into a hipGraph: a graph replays on whatever stream it is launched on, so its launch must not share the slot of the
 // stream it happened to be captured on (an executable graph never runs concurrently with itself).
 // Zero at rest: the last workgroup of a launch resets its slot, so launches need no memset and replay correctly.
-__device__ unsigned int g_sched[kSchedSlots + kGraphSlots][2];
+// A slot holds one queue head per XCD and the count of finished workgroups, each on a 128-byte line of its own (word
+// 32 q, q = 0..7; word 256): the tiles of a launch are cut into eight contiguous ranges, a workgroup pulls from the range
+// of the XCD it runs on (s_getreg XCC_ID) until it is empty and then helps the next two XCDs -- the workgroups that
+// share an L2 work on the same frames (4.74 -> 4.54 ms on the bench batch, 11.45 -> 10.74 ms on config 5's shard).
+// Helping is for balance and is kept short (one workgroup in sixteen goes round all eight queues, so that a range
+// whose XCD runs no workgroup of the launch -- CU masks -- is drained all the same): a failing pull is an atomic on a contended line (~90 per us per line), and with all heads on one line
+// and every workgroup trying all eight at the end a single frame took 188 instead of 97 us.
+constexpr int kSchedStride = 32;                 // words between two counters
+constexpr int kSchedWords = 9 * kSchedStride;
+constexpr uint32_t kStealFrom = 2;               // neighbours a workgroup helps once its own range is empty
+constexpr uint32_t kXcdQueuesFrom = 64;          // launches with fewer workgroups keep one queue
+__device__ unsigned int g_sched[kSchedSlots + kGraphSlots][kSchedWords];
 
 // ---- node records --------------------------------------------------------------------------
 // Hot record, 16 bytes, one 128-bit load per node.  Each word carries a numerator in its high 23 bits, a zero
@@ -260,12 +271,34 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
     const char *depth_b = reinterpret_cast<const char *>(a.depth);
     const int tw = a.tw, th = a.th, twp = a.twp;
     uint32_t static_tile = block_id;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 7u;   // HW_REG_XCC_ID: the XCD this workgroup runs on
+    uint32_t q_empty = 0u;                   // (thread 0) queues found empty so far
 
     for (uint32_t it = 0;; ++it) {
         // ---- take the next tile: 64 label columns x tile_rows label rows of one image ----
         uint32_t tile;
         if (a.sched) {
-            if (tid == 0) s_tile[it & 1u] = atomicAdd(a.sched, 1u);
+            if (tid == 0) {
+                uint32_t t = a.n_tiles;      // nothing left anywhere
+                if (n_blocks < kXcdQueuesFrom) {            // a small launch: one queue (head 0) over all tiles
+                    const uint32_t got = atomicAdd(a.sched, 1u);
+                    if (got < a.n_tiles) t = got;
+                } else {
+                    // nothing guarantees that every XCD runs a workgroup of this launch (CU masks), so some workgroups
+                    // -- eight consecutive ones in every 128, workgroups 0-7 always among them -- go round all queues
+                    const uint32_t reach = ((block_id >> 3) & 15u) == 0u ? 7u : kStealFrom;
+                    for (uint32_t k = 0; k <= reach; ++k) {
+                        const uint32_t q = (xcc + k) & 7u;
+                        if ((q_empty >> q) & 1u) continue;
+                        const uint32_t lo = (uint32_t)(((unsigned long long)a.n_tiles * q) >> 3);
+                        const uint32_t hi = (uint32_t)(((unsigned long long)a.n_tiles * (q + 1u)) >> 3);
+                        const uint32_t got = lo < hi ? atomicAdd(a.sched + q * kSchedStride, 1u) : hi;
+                        if (lo < hi && got < hi - lo) { t = lo + got; break; }
+                        q_empty |= 1u << q;
+                    }
+                }
+                s_tile[it & 1u] = t;
+            }
             __syncthreads();   // also: every wave is done with the previous tile's LDS image
             tile = s_tile[it & 1u];
         } else {
@@ -622,10 +655,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
     // ---- queue epilogue: the last workgroup to finish puts the slot back to zero (every
     // workgroup has made its final, failing pull before it gets here) ----
     if (a.sched && tid == 0) {
-        const unsigned int done = atomicAdd(a.sched + 1, 1u);
+        const unsigned int done = atomicAdd(a.sched + 8 * kSchedStride, 1u);
         if (done == n_blocks - 1u) {
-            atomicExch(a.sched + 0, 0u);
-            atomicExch(a.sched + 1, 0u);
+            for (int q = 0; q < 9; ++q) atomicExch(a.sched + q * kSchedStride, 0u);
         }
     }
 
@@ -879,7 +911,7 @@ unsigned int *sched_slot(void *stream, int role = 0)
         cap == hipStreamCaptureStatusActive) {
         int &n = g_graph_next[dev];
         if (n >= kGraphSlots) return nullptr;   // static tiles: slower on uneven batches, never wrong
-        return bit->second + 2 * (kSchedSlots + n++);
+        return bit->second + kSchedWords * (kSchedSlots + n++);
     }
     const auto key = std::make_tuple(dev, stream, role);
     auto it = g_sched_slot.find(key);
@@ -895,7 +927,7 @@ unsigned int *sched_slot(void *stream, int role = 0)
         if (slot < 0) return nullptr;
         it = g_sched_slot.emplace(key, slot).first;
     }
-    return bit->second + 2 * it->second;
+    return bit->second + kSchedWords * it->second;
 }
 
 // CUs a stream's kernels may run on (hipExtStreamCreateWithCUMask), cached per stream handle.

@@ -250,7 +250,7 @@ int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
 /* A stream whose kernels leave the first n_reserved CUs (hipExtStreamCreateWithCUMask numbering; use a multiple of 32 =
  * one CU per shader engine on MI355X) to other streams, for running the forest kernel next to RCCL: DESIGN.md section 6.
  * rdf_stream_destroy waits for the stream's work, gives its tile-queue slot back and destroys it (call it for any stream
- * that launched forest kernels and is going away: a device has 256 stream slots; beyond them launches fall back to
+ * that launched forest kernels and is going away: a device has 128 stream slots; beyond them launches fall back to
  * static tiles). */
 int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved);
 int rdf_stream_destroy(void *stream);

@@ -552,10 +552,49 @@ def test_cu_masked_stream_sizes_the_grid_on_the_reference_layout_path_too(rdf, e
         assert lib.rdf_stream_destroy(h) == 0
 
 
+@pytest.mark.parametrize("pattern", ["first_ses", "every_8th", "low_word", "one_cu"])
+def test_xcd_queues_are_drained_when_some_xcds_run_no_workgroup(pattern, rdf, evs, oracle, gpu_runtime):
+    """The tile queues are per XCD (a workgroup drains its own XCD's range and helps two neighbours); a CU mask may leave
+    whole XCDs without a workgroup of the launch, whose ranges the workgroups that go round all queues must drain.
+    Streams with CU masks of several shapes (whatever the bit -> XCD numbering is, some of them empty some XCDs), a
+    launch of more than 64 workgroups so that the per-XCD queues are in use: the oracle's labels, twice in a row (the
+    slot resets itself)."""
+    import ctypes
+    import torch
+    lib = gpu_runtime.lib
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    bits = {"first_ses": [i for i in range(n_cu) if i % 32 < 4], "every_8th": [i for i in range(n_cu) if i % 8 == 0],
+            "low_word": list(range(32)), "one_cu": [5]}[pattern]
+    words = (ctypes.c_uint32 * 8)()
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    h = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words) == 0
+    try:
+        forest_np = rdf.synth.forest(4, 10, 4, "trained", first_tree=61)
+        depth = rdf.synth.mixed_batch(24 if pattern != "one_cu" else 3, first_idx=4700, h=240, w=424)
+        want = np.full(depth.shape, 65535, np.uint16)
+        oracle.eval_forest(depth, forest_np, want)
+        forest = rdf.DecisionForest.from_numpy(forest_np)
+        d_dev = rdf.to_device(depth)
+        out = rdf.DeviceArray(depth.shape, np.uint16)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.ExternalStream(h.value)):
+            for name in ("packed", "direct"):
+                for _ in range(2):
+                    out.fill(65535)
+                    evs[name].get_labels_forest(forest, d_dev, out)
+                    assert np.array_equal(out.get(), want), (pattern, name)
+    finally:
+        torch.cuda.synchronize()
+        assert lib.rdf_stream_destroy(h) == 0
+
+
 def test_destroyed_streams_give_their_queue_slots_back(rdf, evs, oracle, gpu_runtime):
-    """A device has 256 tile-queue slots for streams; rdf_stream_destroy returns a stream's slot, so a program that
+    """A device has 128 tile-queue slots for streams; rdf_stream_destroy returns a stream's slot, so a program that
     creates and destroys more streams than that keeps the dynamic queue (round 1 leaked the slot and fell back to
-    static tiles for good after 256 streams)."""
+    static tiles for good after that many streams)."""
     import ctypes
     import torch
     lib = gpu_runtime.lib

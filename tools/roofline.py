@@ -14,8 +14,15 @@ MI355X_MICROARCH.md for the peaks):
     WRITE_SIZE is exact.  Infinity-Cache hits are included, so this is an upper bound of what HBM itself delivers.
   * TCP_TCC_READ_REQ counts 128-byte line requests (one per line for every access width): L2->L1 bytes = requests x 128,
     peak 64 B/clk/CU.
-  * L1/TA pipeline: a divergent wave-level load holds the CU's address/tag pipeline 0.6 cycles per line served by L1 and
-    2.35 cycles per line that has to be filled from L2 (tools/ubench_vmem.hip).
+  * L1/TA pipeline: cycles a CU's vector-memory pipeline needs per 128-byte line access of a divergent load, as a
+    function of the share of those accesses that are filled from L2 (tools/ubench_l1_fill.hip, shader clock measured
+    in the run with s_memtime / s_memrealtime = 2.39 GHz; the share read back with TCP_TCC_READ_REQ /
+    TCP_TOTAL_CACHE_ACCESSES): 0.59 cycles when the L1 serves everything, 2.28 when everything is a fill, and in
+    between close to max(0.59, 0.08 + 2.24 x share) -- fills and hits overlap, the fill path (2.24 cycles per line =
+    57 B/clk/CU of the 64 B/clk/CU L2->L1 interface) is the limiter from a share of a quarter up.  Round 1's two
+    constants (0.6 per hit + 2.35 per fill, added up, cycles derived from wall time at an assumed 2.4 GHz) overstated
+    this level by 15-25 % at the kernel's fill share of about one half and put it above 1.0 once the kernel got faster;
+    the curve agrees with the hardware's own TA_TA_BUSY (0.78 against 0.79 on the bench batch).
   * VALU issue with more than one wave per SIMD: 2.35 cycles for the simple integer/fp32 instructions, 4.2 cycles for
     v_pk_*_f32, conversions, v_perm_b32 and the three-operand integer forms (tools/ubench_valu.hip); the kernel's mix is
     counted in its ISA (VALU_MIX below).
@@ -36,8 +43,10 @@ L2_L1_BYTES_PER_CLK_PER_CU = 64.0
 LINE = 128
 CUS = 256
 SIMDS = 4 * CUS
-TA_CYCLES_PER_L1_HIT = 0.6     # profiles/r01_ubench_vmem.txt: 38.6 cycles per 64-line instruction served by L1
-TA_CYCLES_PER_L2_FILL = 2.35   # ... 151 cycles per 64-line instruction served by L2
+# profiles/r02_ubench_l1_fill.txt: (share of L1 line accesses filled from L2, cycles per line access per CU); the same
+# for 2- and 16-byte loads and for 5 x 256 and 3 x 512 threads per CU
+L1_CYCLES_PER_ACCESS = [(0.0, 0.592), (0.171, 0.633), (0.315, 0.827), (0.452, 1.097), (0.573, 1.354), (0.811, 1.881),
+                        (0.984, 2.285), (1.0, 2.32)]
 VALU_FULL_RATE_CYCLES = 2.35   # profiles/r02_ubench_valu.txt
 VALU_HALF_RATE_CYCLES = 4.2
 # share of the walk loop's VALU instructions that issue at the half rate (v_pk_*, v_cvt_*, v_perm, v_mad_u32_u24,
@@ -111,6 +120,14 @@ def collect(cmd, kernel_substr, timeout=240, passes=PASSES, keep_dir=None):
     return name, out, log
 
 
+def l1_cycles_per_access(share):
+    pts = L1_CYCLES_PER_ACCESS
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if share <= x1:
+            return y0 + (y1 - y0) * (share - x0) / (x1 - x0)
+    return pts[-1][1]
+
+
 def model(counters, kernel_ms, alg_bytes=None, cus=CUS):
     """The four levels for one launch; returns the `roofline` object of bench.py's JSON line."""
     t = kernel_ms * 1e-3
@@ -150,16 +167,17 @@ def model(counters, kernel_ms, alg_bytes=None, cus=CUS):
     # ---- L1 / texture-addresser pipeline ----
     acc = c.get("TCP_TOTAL_CACHE_ACCESSES_sum")
     if fills is not None and acc is not None:
-        hits = max(acc - fills, 0.0)
-        ta_cycles = (hits * TA_CYCLES_PER_L1_HIT + fills * TA_CYCLES_PER_L2_FILL) / cus
+        share = min(fills / acc, 1.0) if acc else 0.0
+        ta_cycles = acc * l1_cycles_per_access(share) / cus
         levels["l1_ta"] = {"achieved": round(ta_cycles / 1e6, 3), "peak": round(cyc / 1e6, 3), "unit": "Mcycles per CU",
                            "frac": round(ta_cycles / cyc, 4), "l1_line_accesses_per_launch": int(acc),
+                           "fill_share": round(share, 4), "cycles_per_line_access": round(l1_cycles_per_access(share), 3),
                            # cross-check from the hardware's own busy counter (cycles the texture addresser is busy,
                            # summed over the CUs, in the profiled pass that collected it)
                            "ta_busy_frac_counter": (round(c["TA_TA_BUSY_sum"] / cus / (c["_ns:TA_TA_BUSY_sum"] * 1e-9 * clk_used), 4)
                                                     if c.get("TA_TA_BUSY_sum") and c.get("_ns:TA_TA_BUSY_sum") else None),
-                           "what": f"(L1 line accesses - fills) x {TA_CYCLES_PER_L1_HIT} + fills x {TA_CYCLES_PER_L2_FILL} "
-                                   "cycles (tools/ubench_vmem.hip) per CU against the kernel's cycles"}
+                           "what": "L1 line accesses x the measured cycles per access at this launch's fill share "
+                                   "(tools/ubench_l1_fill.hip) per CU against the kernel's cycles"}
     # ---- VALU issue ----
     valu = c.get("SQ_INSTS_VALU")
     if valu is not None:

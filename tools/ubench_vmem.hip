@@ -13,10 +13,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 template <int WIDTH, int MODE>   // WIDTH 2 or 16 bytes; MODE 0 plain, 1 sc1, 2 sc0 sc1, 3 nt
-__global__ __launch_bounds__(256) void k_loads(const char *buf, uint32_t window, int nact, int iters, uint32_t *out, uint32_t distinct = 64, int runs = 0)
+__global__ __launch_bounds__(256) void k_loads(const char *buf, uint32_t window, int nact, int iters, uint32_t *out, uint32_t distinct = 64, int runs = 0,
+                                                 unsigned long long *spans = nullptr)
 {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_id = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const bool active = ((lane * 37u) & 63u) < (uint32_t)nact;   // scattered lanes, like far probes
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256) void k_loads(const char *buf, uint32_t window,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (acc == 0x12345u) out[0] = acc;   // keep the loads
+    if (spans && lane == 0) spans[wave_id] = __builtin_amdgcn_s_memtime() - t0;   // this wave's span on the shader clock
 }
 
 int main()
@@ -98,5 +103,27 @@ int main()
         }
         printf("%s %8u  %8.1f\n", runs ? "runs       " : "interleaved", distinct, ms * 1e-3 * 2.4e9 / (5.0 * 4.0 * iters * 8.0));
     }
+    // the two constants of tools/roofline.py's L1/TA level, on the shader clock itself (s_memtime) and as wall time:
+    // 64 lanes, 64 distinct lines per instruction, served by L1 (16 KB window) and by L2 (2 MB window)
+    unsigned long long *spans; hipMalloc(&spans, sizeof(unsigned long long) * grid * 4);
+    std::vector<unsigned long long> h(grid * 4);
+    printf("calibration: width window  cycles_per_line_per_CU (median wave span, s_memtime)  ns_per_line_per_CU (wall)  implied GHz\n");
+    for (int width : {2, 16})
+        for (int w = 0; w < 2; ++w) {
+            float ms = 0;
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0, 0);
+                if (width == 2) hipLaunchKernelGGL((k_loads<2, 0>), dim3(grid), dim3(256), 0, 0, buf, windows[w], 64, iters, out, 64u, 0, spans);
+                else hipLaunchKernelGGL((k_loads<16, 0>), dim3(grid), dim3(256), 0, 0, buf, windows[w], 64, iters, out, 64u, 0, spans);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+            }
+            hipMemcpy(h.data(), spans, sizeof(unsigned long long) * grid * 4, hipMemcpyDeviceToHost);
+            std::sort(h.begin(), h.end());
+            const double lines_per_cu = 5.0 * 4.0 * iters * 8.0 * 64.0;
+            const double cyc = (double)h[h.size() / 2] / lines_per_cu, ns = ms * 1e6 / lines_per_cu;
+            printf("calibration: %5d %-10s  %6.3f  %6.3f  %5.2f\n", width, wname[w], cyc, ns, cyc / ns);
+        }
     return 0;
 }
