@@ -300,7 +300,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
                 s_tile[it & 1u] = t;
             }
             __syncthreads();   // also: every wave is done with the previous tile's LDS image
-            tile = s_tile[it & 1u];
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tile[it & 1u]);   // scalar: the tile's geometry and image base stay in SGPRs
         } else {
             __syncthreads();
             tile = static_tile;
