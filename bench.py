@@ -19,6 +19,9 @@ Rank 0 prints ONE JSON line.  At N = 1 the same run also measures
   * `roofline` objects for the headline kernel, config 2 and config 5: a hierarchical roofline (tools/roofline.py) built
     from rocprofv3 counters that THIS run collects -- before it touches the GPU itself it starts itself once per counter
     set as `rocprofv3 --pmc ... -- python3 bench.py --leg <name>` (separate passes, never combined with tracing),
+  * (N > 1 only) `cfg5_all_ranks`: config 5's workload sharded over the same ranks (32 dense 1280x720 frames and the
+    replicated T8/D22 forest per rank: at N = 8 this is BASELINE configs[4] itself), timed without and with an RCCL
+    gather of the label maps to rank 0, barrier + synchronize on both sides, MAX over ranks, gather verified by checksums,
   * `cpu_baseline`: this repo's CPU restatement (oracle/rdf_oracle.c, OpenMP) -- the reference has no CPU path --
     timed on a bounded sample of the same frames, which also checks the GPU labels of those frames bit for bit.
 """
@@ -59,6 +62,8 @@ def parse():
                     "then come from the committed profiles/r02_roofline_counters.json and say so)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the config-5 shard leg (2 GiB forest)")
     ap.add_argument("--cfg5-frames", type=int, default=32)
+    ap.add_argument("--cfg5-trees", type=int, default=8, help="(tests shrink the config-5 forest)")
+    ap.add_argument("--cfg5-depth", type=int, default=22)
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer variant (pinned H2D + kernel + D2H)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed batch (no other legs, no counters): "
                     "what tools/profile.sh traces so that rocprofv3's per-kernel average is the headline kernel's")
@@ -151,7 +156,8 @@ def collect_counters(a, legs):
     out = {}
     shape = ["--frames", str(a.frames), "--height", str(a.height), "--width", str(a.width), "--trees", str(a.trees),
              "--depth", str(a.depth), "--classes", str(a.classes), "--topology", a.topology, "--scheduler", a.scheduler,
-             "--cfg5-frames", str(a.cfg5_frames)] + (["--unpacked"] if a.unpacked else [])
+             "--cfg5-frames", str(a.cfg5_frames), "--cfg5-trees", str(a.cfg5_trees), "--cfg5-depth", str(a.cfg5_depth)] \
+        + (["--unpacked"] if a.unpacked else [])
     for leg in legs:
         cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--steps", "3", "--warmup", "1"] + shape
         t0 = time.perf_counter()
@@ -229,7 +235,7 @@ def main():
     # Infinity Cache), one launch per step; two frames compared with the oracle
     # ================================================================================================================
     def leg_cfg5(steps, warmup, check):
-        F5, H5, W5, T5, D5, C5 = a.cfg5_frames, 720, 1280, 8, 22, 4
+        F5, H5, W5, T5, D5, C5 = a.cfg5_frames, 720, 1280, a.cfg5_trees, a.cfg5_depth, 4
         f_np = cached(f"forest_T{T5}_D{D5}_C{C5}_full", lambda: synth.forest(T5, D5, C5, "full"))
         fr_np = cached(f"frames_dense_{F5}_{H5}x{W5}_at5000", lambda: synth.frames(["dense"] * F5, 5000, H5, W5))
         forest5 = rdf.DecisionForest.from_numpy(np.asarray(f_np))
@@ -275,6 +281,82 @@ def main():
     if a.leg == "cfg5":
         print(json.dumps({"leg": "cfg5", **leg_cfg5(a.steps, a.warmup, False)}), flush=True)
         return
+
+    def leg_cfg5_all_ranks(steps, warmup):
+        """Config 5 itself at N > 1 (BASELINE configs[4]: 256 frames on 8 GPUs = this leg at N = 8): every rank evaluates
+        its own shard of dense 1280x720 frames with the replicated T8/D22 forest; timed once without and once with the
+        label maps gathered to rank 0 (plain RCCL gather, 59 MB per rank and step) inside the timed region; barrier +
+        synchronize on both sides, MAX over ranks.  Every rank reaches every collective: a rank that cannot get its inputs
+        says so through the first all_reduce and the leg is skipped everywhere."""
+        F5, H5, W5, T5, D5, C5 = a.cfg5_frames, 720, 1280, a.cfg5_trees, a.cfg5_depth, 4
+        ok, f_np, fr_np, err = 1, None, None, None
+        name = f"forest_T{T5}_D{D5}_C{C5}_full"
+        try:
+            if rank == 0:
+                f_np = cached(name, lambda: synth.forest(T5, D5, C5, "full"))   # the others find it in the cache
+        except Exception as e:   # noqa: BLE001
+            ok, err = 0, repr(e)
+        dist.barrier()
+        try:
+            if rank != 0:
+                f_np = cached(name, lambda: synth.forest(T5, D5, C5, "full"))
+            fr_np = cached(f"frames_dense_{F5}_{H5}x{W5}_at{5000 + rank * F5}",
+                           lambda: synth.frames(["dense"] * F5, 5000 + rank * F5, H5, W5))
+        except Exception as e:   # noqa: BLE001
+            ok, err = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return {"skipped": err or "another rank could not build its inputs"}
+        forest5 = rdf.DecisionForest.from_numpy(np.asarray(f_np))
+        depth5 = rdf.to_device(np.asarray(fr_np))
+        lab5 = rdf.DeviceArray((F5, H5, W5), np.uint16).fill(65535)
+        if not a.unpacked:
+            forest5.packed(1.0)
+        mine = lab5.torch_bytes()           # uint8: every backend gathers bytes
+        slabs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+
+        def run(with_gather):
+            for _ in range(warmup):
+                ev.get_labels_forest(forest5, depth5, lab5)
+                if with_gather:
+                    dist.gather(mine, slabs, dst=0)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ev.get_labels_forest(forest5, depth5, lab5)
+                if with_gather:
+                    dist.gather(mine, slabs, dst=0)
+            sync_all()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        t_kernel = run(False)
+        t_gather = run(True)
+        # did rank 0 receive every rank's label maps?  (checksums, as for the headline)
+        m64 = mine.view(torch.int16).to(torch.int64)
+        sums = torch.stack([m64.sum(), (m64 * (torch.arange(m64.numel(), device=m64.device) % 8191)).sum()])
+        allsums = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(allsums, sums)
+        check = None
+        if rank == 0:
+            check = "ok"
+            for g in range(world):
+                p64 = slabs[g].view(torch.int16).to(torch.int64)
+                chk = torch.stack([p64.sum(), (p64 * (torch.arange(p64.numel(), device=p64.device) % 8191)).sum()])
+                if not torch.equal(chk, allsums[g]):
+                    check = "MISMATCH"
+        pix = world * F5 * H5 * W5
+        res = {"value": round(pix * steps / t_gather / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(t_gather / steps * 1e3, 4),
+               "value_kernel_only": round(pix * steps / t_kernel / 1e6, 2), "kernel_only_ms": round(t_kernel / steps * 1e3, 4),
+               "n_gpus": world, "steps": steps, "warmup": warmup, "gather": "rccl gather to rank 0 inside the timed region",
+               "gather_check": check, "scaling": "weak",
+               "workload": f"{world} x {F5} dense {W5}x{H5} frames, T{T5}/D{D5}/C{C5} full forest replicated "
+                           f"(config 5{' itself' if world * F5 == 256 else ' shards'}), {world} GPUs"}
+        del forest5, depth5, lab5, slabs
+        torch.cuda.empty_cache()
+        return res
 
     # ================================================================================================================
     # headline workload
@@ -470,6 +552,10 @@ def main():
                                                    "cus_left_to_rccl": r["reserve"], "gather_check": r["gather_check"]}
                                                for n, r in results.items()}}
 
+        if not a.no_cfg5:
+            c5n = leg_cfg5_all_ranks(5, 2)       # every rank takes part
+            out["cfg5_all_ranks"] = c5n
+
     key = f"F{F}_T{T}_D{D}_C{C}_{a.topology}"
     out["roofline"] = roofline_for("headline", key, live, kern_avg_ms, alg_bytes)
     out["roofline"]["algorithmic"].update({"bytes_per_pixel": round(alg_bytes / (F * H * W), 1),
@@ -618,7 +704,7 @@ def main():
             del forest, depth, labels, scratch, sharded, lf
             torch.cuda.empty_cache()
             c5 = leg_cfg5(5, 2, True)
-            c5["roofline"] = roofline_for("cfg5", f"F{a.cfg5_frames}_T8_D22_C4_full_1280x720", live, c5["kernel_ms"],
+            c5["roofline"] = roofline_for("cfg5", f"F{a.cfg5_frames}_T{a.cfg5_trees}_D{a.cfg5_depth}_C4_full_1280x720", live, c5["kernel_ms"],
                                           c5.pop("algorithmic_bytes", None))
             out["cfg5_shard"] = c5
         if live:

@@ -46,7 +46,8 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
     env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--frames", "6", "--depth", "12", "--backend", "gloo", "--gather", gather, "--reserve-cus", "0"]
+           "--frames", "6", "--depth", "12", "--backend", "gloo", "--gather", gather, "--reserve-cus", "0",
+           "--cfg5-frames", "2", "--cfg5-trees", "3", "--cfg5-depth", "12"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
@@ -57,3 +58,6 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
     assert all(m["gather_check"] == "ok" for m in dd["gather_modes"].values())
     assert ("p2p" in d["config"]["gather"]) == (gather in ("p2p", "both"))
     assert len(dd["gather_modes"]) == (2 if gather == "both" else 1)
+    # config 5's workload sharded over the same ranks (1280x720 dense frames; the forest shrunk for the test)
+    c5 = d["cfg5_all_ranks"]
+    assert c5["n_gpus"] == 2 and c5["gather_check"] == "ok" and c5["value"] > 0 and c5["value_kernel_only"] >= c5["value"]
