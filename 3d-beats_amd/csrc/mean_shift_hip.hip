@@ -27,20 +27,37 @@ constexpr uint32_t kMsListCap = 32768;   // pixels of one class kept in LDS (131
 constexpr uint32_t kMsTabCap = 3072;     // dim_x + dim_y the per-round weight tables cover (24 576 B)
 constexpr int kMsSteps = 13;             // 16 waves x 13 steps x 512 pixels = 106 496 >= the app's 424 x 240 label map
 
-__device__ __forceinline__ double wave_sum(double v)
+// One step of a row-wise (16 lanes) sum: v += the value `shr` lanes to the left in the same row (0.0 where there is none).
+// DPP moves of the two halves: a VALU-speed lane exchange (ds_bpermute, which __shfl_down compiles to, is an LDS round trip).
+template <int SHR>
+__device__ __forceinline__ double row_add_shr(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);   // fixed tree => reproducible
-    return v;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SHR, 0xF, 0xF, true);   // row_shr:SHR, bound_ctrl: 0 outside
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SHR, 0xF, 0xF, true);
+    return v + __hiloint2double(phi, plo);
 }
 
-// Sum of every thread's (a, b, c) in a fixed order: shuffle tree inside a wave, then the waves one after the other.
-// Every thread returns with the totals in tot[0..2].
+// Sum over the wave in a fixed order: a shift-add scan inside each row of 16 lanes (lane 15, 31, 47, 63 then hold their
+// row's total), the four row totals added in order.  Every lane returns the same value.
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = row_add_shr<1>(v); v = row_add_shr<2>(v); v = row_add_shr<4>(v); v = row_add_shr<8>(v);
+    double r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        r[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * q + 15),
+                                __builtin_amdgcn_readlane(__double2loint(v), 16 * q + 15));
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
+
+// Sum of every thread's (a, b, c) in a fixed order: inside a wave as above, then the waves one after the other.
+// Every thread returns with the totals in tot[0..2].  s_red is double-buffered by the caller's round parity, so one
+// barrier per call is enough: a buffer is rewritten two calls later, after every thread has passed the barrier between.
 __device__ __forceinline__ void block_sum3(double a, double b, double c, double (*s_red)[3], double *tot)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
-    __syncthreads();                       // the previous call's readers are done with s_red
     if (lane == 0) { s_red[wave][0] = a; s_red[wave][1] = b; s_red[wave][2] = c; }
     __syncthreads();
     double ta = 0.0, tb = 0.0, tc = 0.0;
@@ -61,13 +78,14 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
 {
     extern __shared__ uint32_t s_list[];
     __shared__ double s_tab[kMsTabCap];      // round's weights by column, then by row (see the rounds below)
-    __shared__ double s_red[kMsWaves][3];
+    __shared__ double s_red[2][kMsWaves][3];
     __shared__ uint32_t s_wave_cnt[kMsWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t want = blockIdx.x + 1u;
     const uint32_t n_px = (uint32_t)dim_x * (uint32_t)dim_y;
 
-    // ---- list this class's pixels.  A wave takes kMsSteps x 512 consecutive pixels per batch, eight per lane and step
+    // ---- list this class's pixels.  A wave takes kMsSteps x 512 pixels per batch (512 consecutive ones per step, the
+    // sixteen waves interleaved), eight per lane and step
     // (one 16-byte load; a step's eight match bits are one byte of a packed register); a lane's pixels go to consecutive
     // list slots, the lanes of a wave, the waves and the batches follow each other in order -- positions come from a
     // wave scan of the per-lane counts and the waves' totals, so the order does not depend on timing (the rounds' sums
@@ -76,14 +94,18 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
     const bool vec_ok = (reinterpret_cast<uintptr_t>(labels) & 15u) == 0u;
     uint32_t n_class = 0;
     for (uint32_t batch0 = 0; batch0 < n_px; batch0 += kMsWaves * kMsSteps * 512u) {
-        const uint32_t wbase = batch0 + (uint32_t)wave * (kMsSteps * 512u);
+        // step k of wave w covers the 512 pixels from batch0 + (k * 16 + w) * 512: a class is a few blobs, and with the
+        // waves interleaved every 512 pixels all sixteen share the work of listing it (a wave alone on its SIMD issues
+        // an instruction every ~8 cycles: with 16 consecutive rows per wave, the one or two waves that held a fingertip
+        // took 13 000 cycles to list 140 pixels while the others idled)
+        const uint32_t wbase = batch0 + (uint32_t)wave * 512u;
         uint32_t mp[(kMsSteps + 3) / 4];      // byte k & 3 of word k >> 2: which of the lane's eight pixels of step k match
 #pragma unroll
         for (int q = 0; q < (kMsSteps + 3) / 4; ++q) mp[q] = 0u;
         uint32_t cnt = 0u;
 #pragma unroll
         for (int k = 0; k < kMsSteps; ++k) {
-            const uint32_t p0 = wbase + ((uint32_t)k * 64u + (uint32_t)lane) * 8u;
+            const uint32_t p0 = wbase + ((uint32_t)k * (kMsWaves * 64u) + (uint32_t)lane) * 8u;
             uint32_t bits = 0u;
             if (p0 + 8u <= n_px && vec_ok) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(labels + p0);
@@ -117,18 +139,31 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
         if (cnt != 0u && at < kMsListCap) {      // (a lane whose first slot is beyond the list writes nothing: the class overflows)
 #pragma unroll
             for (int k = 0; k < kMsSteps; ++k) {
-                uint32_t mk = (mp[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const uint32_t mk = (mp[k >> 2] >> (8 * (k & 3))) & 0xFFu;
                 if (mk == 0u) continue;
-                const uint32_t p0 = wbase + ((uint32_t)k * 64u + (uint32_t)lane) * 8u;
+                const uint32_t p0 = wbase + ((uint32_t)k * (kMsWaves * 64u) + (uint32_t)lane) * 8u;
                 const uint32_t y0 = p0 / (uint32_t)dim_x, x0 = p0 - y0 * (uint32_t)dim_x;   // one division per eight pixels
-                while (mk) {
-                    const uint32_t j = (uint32_t)__builtin_ctz(mk);
-                    mk &= mk - 1u;
-                    uint32_t x = x0 + j, y = y0;
-                    while (x >= (uint32_t)dim_x) { x -= (uint32_t)dim_x; ++y; }              // (rows narrower than 8 wrap more than once)
-                    if (at < kMsListCap) s_list[at] = x | (y << 16);
-                    ++at;
+                if (dim_x >= 8) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j) {      // the eight pixels sit in at most two rows
+                        if ((mk >> j) & 1u) {
+                            const uint32_t xj = x0 + j, wrap = xj >= (uint32_t)dim_x ? 1u : 0u;
+                            const uint32_t slot = at + (uint32_t)__builtin_popcount(mk & ((1u << j) - 1u));
+                            if (slot < kMsListCap) s_list[slot] = (xj - (wrap ? (uint32_t)dim_x : 0u)) | ((y0 + wrap) << 16);
+                        }
+                    }
+                } else {
+                    uint32_t rest = mk, slot = at;
+                    while (rest) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(rest);
+                        rest &= rest - 1u;
+                        uint32_t x = x0 + j, y = y0;
+                        while (x >= (uint32_t)dim_x) { x -= (uint32_t)dim_x; ++y; }      // (rows narrower than 8 wrap more than once)
+                        if (slot < kMsListCap) s_list[slot] = x | (y << 16);
+                        ++slot;
+                    }
                 }
+                at += (uint32_t)__builtin_popcount(mk);
             }
         }
         n_class += batch_total;
@@ -148,7 +183,8 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
     for (int round = 0; round < num_rounds; ++round) {
         double sx = 0.0, sy = 0.0, sw = 0.0;
         if (round > 0 && tables) {
-            __syncthreads();                 // the previous round's readers are done with the tables
+            // (no barrier before rewriting the tables: every thread has passed the barrier of the previous round's
+            // block_sum3, which it reaches only after its last table read)
             for (uint32_t i = tid; i < (uint32_t)dim_x + (uint32_t)dim_y; i += kMsThreads) {
                 const double c = i < (uint32_t)dim_x ? (double)(int)i - mx : (double)(int)(i - (uint32_t)dim_x) - my;
                 s_tab[i] = exp(-(c * c) / (2 * v_2));
@@ -171,14 +207,34 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
                 sx += dx * w; sy += dy * w; sw += w;
             }
         };
-        for (uint32_t i = tid; i < n_list; i += kMsThreads) {
-            const uint32_t e = s_list[i];
-            term(e & 0xFFFFu, e >> 16);
+        if (round > 0 && tables) {
+            // four list entries per trip, their table reads in flight together; added in the same order as one by one
+            for (uint32_t i = tid; i < n_list; i += 4u * kMsThreads) {
+                uint32_t e[4];
+                double wx[4], wy[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) e[u] = i + u * kMsThreads < n_list ? s_list[i + u * kMsThreads] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) { wx[u] = s_tab[e[u] & 0xFFFFu]; wy[u] = s_tab[(uint32_t)dim_x + (e[u] >> 16)]; }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    if (i + u * kMsThreads < n_list) {
+                        const double dx = (double)(int)(e[u] & 0xFFFFu) - mx, dy = (double)(int)(e[u] >> 16) - my;
+                        const double w = wx[u] * wy[u];
+                        sx += dx * w; sy += dy * w; sw += w;
+                    }
+                }
+            }
+        } else {
+            for (uint32_t i = tid; i < n_list; i += kMsThreads) {
+                const uint32_t e = s_list[i];
+                term(e & 0xFFFFu, e >> 16);
+            }
         }
         for (uint32_t p = rescan_from + tid; p < n_px; p += kMsThreads)
             if (labels[p] == want) term(p % (uint32_t)dim_x, p / (uint32_t)dim_x);
         double tot[3];
-        block_sum3(sx, sy, sw, s_red, tot);
+        block_sum3(sx, sy, sw, s_red[round & 1], tot);
         mx = mx + tot[0] / tot[2];                 // 0/0 = NaN for a class without pixels, as in the reference
         my = my + tot[1] / tot[2];
     }
