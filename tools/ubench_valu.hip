@@ -22,14 +22,16 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 enum Op { FMA = 0, PK_FMA, CVT_F32_I32, CVT_FLR_I32_F32, ADD_U32, PERM_B32, CNDMASK, MAD_U32_U24, LSHL_ADD,
-          CMP_SGPR, CNDMASK_SGPR, MUL_U32_U24, ADD_LSHL, OR3, BFE_I32, LSHLREV, MAX_I32, PK_MUL, MOV, FLOOR_F32, MED3_I32, PK_ADD_I16, CNDMASK_SDWA, ADD_F32, MUL_F32, CMP_CND_VCC, CMP_CND_SGPR, CND_VCC_NEWDST, CND_E64_VCC, N_OPS };
+          CMP_SGPR, CNDMASK_SGPR, MUL_U32_U24, ADD_LSHL, OR3, BFE_I32, LSHLREV, MAX_I32, PK_MUL, MOV, FLOOR_F32, MED3_I32, PK_ADD_I16, CNDMASK_SDWA, ADD_F32, MUL_F32, CMP_CND_VCC, CMP_CND_SGPR, CND_VCC_NEWDST, CND_E64_VCC, SUB_CO_SGPR, ADD_CO_VCC, ADDC_CO_SGPR, CMP_LT_I32_SGPR, CMP_EQ_U32_SGPR, N_OPS };
 static const char *kOpName[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_i32", "v_cvt_flr_i32_f32", "v_add_u32",
                                      "v_perm_b32", "v_cndmask_b32(vcc)", "v_mad_u32_u24", "v_lshl_add_u32",
                                      "v_cmp_gt_u32 -> sgpr", "v_cndmask_b32(sgpr)", "v_mul_u32_u24", "v_add_lshl_u32", "v_or3_b32",
                                      "v_bfe_i32", "v_lshlrev_b32", "v_max_i32", "v_pk_mul_f32", "v_mov_b32", "v_floor_f32",
                                      "v_med3_i32", "v_pk_add_i16", "v_cndmask_b32_sdwa(vcc)", "v_add_f32", "v_mul_f32",
                                      "v_cmp->vcc + v_cndmask(vcc) [pair]", "v_cmp->sgpr + v_cndmask(sgpr) [pair]",
-                                     "v_cndmask_b32(vcc) dst!=src", "v_cndmask_b32_e64(vcc)"};
+                                     "v_cndmask_b32(vcc) dst!=src", "v_cndmask_b32_e64(vcc)",
+                                     "v_sub_co_u32_e64 -> sgpr (borrow = a < b)", "v_add_co_u32_e32 -> vcc", "v_addc_co_u32_e64 (sgpr in/out)",
+                                     "v_cmp_lt_i32 -> sgpr", "v_cmp_eq_u32 -> sgpr"};
 
 #define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 
@@ -170,8 +172,28 @@ __global__ __launch_bounds__(1024) void k_valu(int iters, unsigned long long *st
 #define S(k) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(u[k]) : "v"(ub), "v"(ub));
                 REP8(S)
 #undef S
-            } else {
+            } else if (OP == CND_E64_VCC) {
 #define S(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(u[k]) : "v"(ub));
+                REP8(S)
+#undef S
+            } else if (OP == SUB_CO_SGPR) {
+#define S(k) asm volatile("v_sub_co_u32_e64 %0, %1, %0, %2" : "+v"(u[k]), "=s"(m[k]) : "v"(ub));
+                REP8(S)
+#undef S
+            } else if (OP == ADD_CO_VCC) {
+#define S(k) asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(u[k]) : "v"(ub) : "vcc");
+                REP8(S)
+#undef S
+            } else if (OP == ADDC_CO_SGPR) {
+#define S(k) asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(u[k]), "+s"(m[k]));
+                REP8(S)
+#undef S
+            } else if (OP == CMP_LT_I32_SGPR) {
+#define S(k) asm volatile("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m[k]) : "v"(u[k]), "v"(ub));
+                REP8(S)
+#undef S
+            } else {
+#define S(k) asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m[k]) : "v"(u[k]), "v"(ub));
                 REP8(S)
 #undef S
             }
@@ -286,5 +308,10 @@ int main(int argc, char **argv)
     run_op<CMP_CND_SGPR>(cus, iters, d_st, d_wh);
     run_op<CND_VCC_NEWDST>(cus, iters, d_st, d_wh);
     run_op<CND_E64_VCC>(cus, iters, d_st, d_wh);
+    run_op<SUB_CO_SGPR>(cus, iters, d_st, d_wh);
+    run_op<ADD_CO_VCC>(cus, iters, d_st, d_wh);
+    run_op<ADDC_CO_SGPR>(cus, iters, d_st, d_wh);
+    run_op<CMP_LT_I32_SGPR>(cus, iters, d_st, d_wh);
+    run_op<CMP_EQ_U32_SGPR>(cus, iters, d_st, d_wh);
     return 0;
 }
