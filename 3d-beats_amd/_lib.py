@@ -74,6 +74,7 @@ SIGNATURES = {
     "rdf_set_compaction": (None, [_c_int]),
     "rdf_set_halo": (None, [_c_int]),
     "rdf_set_lds_levels": (None, [_c_int]),
+    "rdf_set_tree_waves": (None, [_c_int]),
     "rdf_set_stage_vec": (None, [_c_int]),
     "rdf_set_group": (None, [_c_int]),
     "rdf_set_layers_one_launch": (None, [_c_int]),

@@ -127,6 +127,7 @@ struct EvalArgs {
     int tw, th, twp;       // staged depth tile: width, height, row pitch (0: no staged tile)
     uint32_t stage_tw8;    // > 0: stage with 16-byte loads, tw / 8 vectors per row (W, tx0 and twp are multiples of 8)
     uint32_t stage_magic;  // floor(2^32 / stage_tw8) + 1: i / stage_tw8 == umulhi(i, magic) for i < 2^32 / stage_tw8
+    uint32_t lds_xchg_off; // (tree waves) where the trees of a pixel row meet
     uint32_t lds_tile_off; // byte offsets inside the dynamic LDS allocation
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
@@ -227,10 +228,10 @@ struct EvalArgsN {
     EvalArgs l[NL];
 };
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT, int NL = 1>
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT, int NL = 1, bool TW = false>
 // second launch bound = waves per SIMD the register allocation must allow: three 512-thread workgroups per CU are six
 // waves per SIMD (80 VGPRs; the 4-wide walk needs 86 without the bound and spills two dwords with it)
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgsN<NL> ka)
+__global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgsN<NL> ka)
 {
     const uint32_t role = NL > 1 ? blockIdx.x % NL : 0u;           // workgroup-uniform
     const uint32_t block_id = NL > 1 ? blockIdx.x / NL : blockIdx.x, n_blocks = NL > 1 ? gridDim.x / NL : gridDim.x;
@@ -247,8 +248,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
     const uint32_t nodes_lds = (1u << K) - 1u;
     constexpr uint32_t kWaves = BLOCK / 64;
     const int rows_per_wave = FULLROWS ? kMaxRowsPerWave : a.rows_per_wave;
-    const uint32_t tile_rows = kWaves * (uint32_t)rows_per_wave;
     const uint32_t wave = (uint32_t)tid >> 6;
+    // TW ("tree waves", small launches): the T trees of a forest are walked by T different waves -- wave w takes tree
+    // w % T for pixel row w / T of the tile -- and meet in LDS.  A wave alone on its SIMD issues an instruction every
+    // ~8 cycles, and a launch of one live frame is a few hundred such waves: its duration is the instruction count of ONE
+    // wave's walk (1.3 us per level with four trees interleaved in a lane, 0.3 us with one; measured), not throughput.
+    const uint32_t tw_T = TW ? (uint32_t)a.T : 1u;
+    const uint32_t tw_row = TW ? wave / tw_T : 0u, tw_tree = TW ? wave - tw_row * tw_T : 0u;
+    const uint32_t tile_rows = TW ? (kWaves / tw_T) * (uint32_t)rows_per_wave : kWaves * (uint32_t)rows_per_wave;
 
     // ---- stage the top K levels of every tree.  Tables use 1-based heap numbering (slot 0 unused):
     // node h has children 2h and 2h+1, which therefore share one aligned 32-byte pair ----
@@ -445,7 +452,49 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
 
         // pixel slots of the tile, row-major (row << 6 | column), 64 per wave step; uncompacted, the rows of the waves
         // are interleaved
-        for (uint32_t first = wave * 64u; first < n_valid; first += BLOCK) {
+        constexpr uint32_t kDone = 0x80000000u, kIdle = 0xFFFFFFFFu;   // walk state of a tree slot: see the level loop
+        // adds the PDF of the leaf a finished walk (state word hk, see the level loop) reached in tree `tree` to pdf[],
+        // classes c0 .. c0 + CMAX - 1; false when the walk reached no leaf (tree_eval.cu:95-128: level D-1 says "continue")
+        auto add_leaf_pdf = [&](uint32_t hk, int tree, int c0, float (&pdf)[CMAX]) -> bool {
+            if (!((int)hk < 0 && hk != kIdle)) return false;
+            const uint32_t leaf = (hk & ~kDone) - 2u;   // (node - 1) * 2 + side
+            if (PACKED) {
+                // one aligned 16-byte load per four classes from the packed PDF table (zero-padded to
+                // cpad), instead of C scalar loads at odd offsets inside the 7+2C-float record: the
+                // scattered leaf reads were a sixth of all L1 accesses
+                const float4 *pp = reinterpret_cast<const float4 *>(a.packed_pdf) +
+                    (((((size_t)tree) << a.D) + (leaf >> 1) + 1u) * 2u + (leaf & 1u)) * (size_t)(a.cpad >> 2) +
+                    (size_t)(c0 >> 2);
+#pragma unroll
+                for (int c = 0; c < CMAX; c += 4) {
+                    if (c0 + c < a.cpad) {
+                        const float4 v = pp[c >> 2];
+                        pdf[c] = pdf[c] + v.x; pdf[c + 1] = pdf[c + 1] + v.y;
+                        pdf[c + 2] = pdf[c + 2] + v.z; pdf[c + 3] = pdf[c + 3] + v.w;
+                    }
+                }
+            } else {
+                const float *pp = a.forest +
+                    ((size_t)tree * (size_t)a.nodes + (leaf >> 1)) * (size_t)a.E +
+                    7 + (leaf & 1u) * a.C + c0;
+#pragma unroll
+                for (int c = 0; c < CMAX; c += 4) {
+                    if (c0 + c + 3 < a.C) {           // four classes with one (4-byte aligned) wide load
+                        const f4u v = *reinterpret_cast<const f4u *>(pp + c);
+                        pdf[c] = pdf[c] + v.x; pdf[c + 1] = pdf[c + 1] + v.y;
+                        pdf[c + 2] = pdf[c + 2] + v.z; pdf[c + 3] = pdf[c + 3] + v.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + c + e < a.C) pdf[c + e] = pdf[c + e] + pp[c + e];
+                    }
+                }
+            }
+            return true;
+        };
+        uint32_t tw_h = kIdle, tw_i = 0u;       // (TW) this wave's tree: where its walk ended for this lane's pixel
+        bool tw_valid = false;
+        for (uint32_t first = TW ? (tw_row < tile_rows ? tw_row * 64u : n_valid) : wave * 64u; first < n_valid; first += BLOCK) {
             const uint32_t slot = first + (uint32_t)lane;
             uint32_t entry = slot;
             if (compact) {
@@ -464,7 +513,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
             uint32_t d = 0u;
             if (!skip) d = (uint32_t)probe_value(probe_issue(pc, xl, yl));
             if (!compact && (skip || d == 0u || d == kNoPixel)) {
-                if (a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
+                if (a.fill_untouched && (!TW || tw_tree == 0u)) a.labels[i] = (uint16_t)kNoPixel;
                 continue;
             }
             const float df = (float)d;
@@ -484,11 +533,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) pdf[c] = 0.0f;
 
-                for (int kb = 0; kb < a.T; kb += GROUP) {
+                for (int kb = TW ? (int)tw_tree : 0; kb < (TW ? (int)tw_tree + 1 : a.T); kb += GROUP) {
                     // Walk state, one word per tree: while walking, the 1-based heap index of the current node
                     // (< 2^31); once a leaf is reached, kDone | ((node - 1) * 2 + side); kIdle for tree slots
                     // beyond T.  "Still walking" is simply (int)h > 0.
-                    constexpr uint32_t kDone = 0x80000000u, kIdle = 0xFFFFFFFFu;
                     uint32_t h[GROUP];
 #pragma unroll
                     for (int k = 0; k < GROUP; ++k) h[k] = (kb + k) < a.T ? 1u : kIdle;
@@ -604,48 +652,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
                         }
                     }
 
+                    if (TW) { tw_h = h[0]; break; }       // the trees meet in LDS, below the pixel loop
                     // leaf PDFs, strictly in tree order (canonical sum order)
 #pragma unroll
                     for (int k = 0; k < GROUP; ++k) {
-                        if ((int)h[k] < 0 && h[k] != kIdle) {
-                            const uint32_t leaf = (h[k] & ~kDone) - 2u;   // (node - 1) * 2 + side
+                        if (add_leaf_pdf(h[k], kb + k, c0, pdf)) {
                             any_leaf = true;
                             if (STATS && c0 == 0) st_lf++;
-                            if (PACKED) {
-                                // one aligned 16-byte load per four classes from the packed PDF table (zero-padded to
-                                // cpad), instead of C scalar loads at odd offsets inside the 7+2C-float record: the
-                                // scattered leaf reads were a sixth of all L1 accesses
-                                const float4 *pp = reinterpret_cast<const float4 *>(a.packed_pdf) +
-                                    (((((size_t)(kb + k)) << a.D) + (leaf >> 1) + 1u) * 2u + (leaf & 1u)) * (size_t)(a.cpad >> 2) +
-                                    (size_t)(c0 >> 2);
-#pragma unroll
-                                for (int c = 0; c < CMAX; c += 4) {
-                                    if (c0 + c < a.cpad) {
-                                        const float4 v = pp[c >> 2];
-                                        pdf[c] = pdf[c] + v.x; pdf[c + 1] = pdf[c + 1] + v.y;
-                                        pdf[c + 2] = pdf[c + 2] + v.z; pdf[c + 3] = pdf[c + 3] + v.w;
-                                    }
-                                }
-                            } else {
-                                const float *pp = a.forest +
-                                    ((size_t)(kb + k) * (size_t)a.nodes + (leaf >> 1)) * (size_t)a.E +
-                                    7 + (leaf & 1u) * a.C + c0;
-#pragma unroll
-                                for (int c = 0; c < CMAX; c += 4) {
-                                    if (c0 + c + 3 < a.C) {           // four classes with one (4-byte aligned) wide load
-                                        const f4u v = *reinterpret_cast<const f4u *>(pp + c);
-                                        pdf[c] = pdf[c] + v.x; pdf[c + 1] = pdf[c + 1] + v.y;
-                                        pdf[c + 2] = pdf[c + 2] + v.z; pdf[c + 3] = pdf[c + 3] + v.w;
-                                    } else {
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e)
-                                            if (c0 + c + e < a.C) pdf[c + e] = pdf[c + e] + pp[c + e];
-                                    }
-                                }
-                            }
                         }
                     }
                 }
+                if (TW) break;
 
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) {
@@ -656,12 +673,44 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) voi
                 }
             }
 
+            if (TW) { tw_valid = true; tw_i = i; continue; }
             if (STATS) st_px++;
             if (a.keep_if_no_leaf && !any_leaf) {
                 if (a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
                 continue;
             }
             a.labels[i] = (uint16_t)best_c;
+        }
+        if (TW) {
+            // ---- the T waves of a pixel row hand their trees' results to the row's first wave, which sums the leaf PDFs
+            // in tree order (the canonical order) and writes the label ----
+            uint32_t *xch = reinterpret_cast<uint32_t *>(lds_raw + a.lds_xchg_off);     // [tile row][tree][lane]
+            if (tw_row < tile_rows) xch[(tw_row * tw_T + tw_tree) * 64u + (uint32_t)lane] = tw_valid ? tw_h : kIdle;
+            __syncthreads();       // (the barrier at the top of the next tile keeps the next round's writers away)
+            if (tw_row < tile_rows && tw_tree == 0u && tw_valid) {
+                float best = 0.0f;
+                int best_c = 0;
+                bool any_leaf = false;
+                for (int c0 = 0; c0 < a.C || c0 == 0; c0 += CMAX) {
+                    float pdf[CMAX];
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) pdf[c] = 0.0f;
+                    for (uint32_t t = 0; t < tw_T; ++t)
+                        any_leaf |= add_leaf_pdf(xch[(tw_row * tw_T + t) * 64u + (uint32_t)lane], (int)t, c0, pdf);
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c0 + c < a.C && pdf[c] > best) {
+                            best = pdf[c];
+                            best_c = c0 + c;
+                        }
+                    }
+                }
+                if (a.keep_if_no_leaf && !any_leaf) {
+                    if (a.fill_untouched) a.labels[tw_i] = (uint16_t)kNoPixel;
+                } else {
+                    a.labels[tw_i] = (uint16_t)best_c;
+                }
+            }
         }
     }
 
@@ -1020,10 +1069,11 @@ int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 
 // NL forests (the layers of a small layered run) in one launch: 256 threads, runtime rows, four trees per lane, no
 // pixel list -- the one geometry every small packed launch can take.
-template <int CMAX, int NL>
+template <int CMAX, int NL, bool TW = false>
 int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st)
 {
-    auto kern = k_eval_forest<256, true, CMAX, false, false, kGroup, false, NL>;
+    constexpr int kBlock = TW ? 1024 : 256;      // tree waves: 16 waves = 16 / T pixel rows x T trees
+    auto kern = k_eval_forest<kBlock, true, CMAX, false, false, TW ? 1 : kGroup, false, NL, TW>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
@@ -1039,16 +1089,18 @@ int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st
             if (e != hipSuccess) return (int)e;
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds_bytes) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kBlock, (size_t)lds_bytes) != hipSuccess || n < 1) n = 1;
         per_cu = n;
         std::lock_guard<std::mutex> lock(g_sched_mu);
         g_occ_cache[key] = per_cu;
     }
     // every role gets the same number of persistent workgroups (all roles have the same tiles: same frame, same reduce)
     long long per_role = (long long)cus * per_cu / NL;
-    if (per_role > (long long)ka.l[0].n_tiles) per_role = ka.l[0].n_tiles;
+    uint32_t most_tiles = 0;     // (tree waves: a role's tile holds 4 / T rows, so the roles' tile counts may differ)
+    for (int l = 0; l < NL; ++l) most_tiles = ka.l[l].n_tiles > most_tiles ? ka.l[l].n_tiles : most_tiles;
+    if (per_role > (long long)most_tiles) per_role = most_tiles;
     if (per_role < 1) per_role = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(per_role * NL)), dim3(256), lds_bytes, st, ka);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_role * NL)), dim3(kBlock), lds_bytes, st, ka);
     return (int)hipGetLastError();
 }
 
@@ -1110,6 +1162,7 @@ int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void 
 
 int g_halo = -1;
 int g_lds_levels = -1;
+int g_tree_waves = -1;
 int g_stage_vec = -1;
 int g_rows_per_wave = 0;
 int g_force_exact = 0;
@@ -1119,13 +1172,13 @@ int g_force_exact = 0;
 struct Plan {
     EvalArgs a;
     int lds_bytes = 0, block = 0;
-    bool big = false, empty = false;
+    bool big = false, empty = false, tw = false;
 };
 
 int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
                 const float *forest, int n_trees, int max_depth, int n_classes, const uint16_t *filter,
                 int filter_class, uint16_t *labels_out, int r, float s, int keep_if_no_leaf,
-                unsigned long long *stats, void *stream, int fill_untouched = 0, Plan *plan_only = nullptr)
+                unsigned long long *stats, void *stream, int fill_untouched = 0, Plan *plan_only = nullptr, bool allow_tw = true)
 {
     int rc = check_common(depth, n_img, dim_x, dim_y, forest, n_trees, max_depth, n_classes, labels_out, r);
     if (rc == 1) {
@@ -1180,15 +1233,26 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         if (big && block == 512) rpw = 2;      // 8 waves x 2 rows: the 64 x 16 tile of four waves x 4 rows
         while (rpw > 1 && (long long)n_img * a.tiles_x * ((a.Hl + rpw - 1) / rpw) < waves_wanted) rpw >>= 1;
     }
+    // Tree waves (k_eval_forest<..., TW>): a small unfiltered packed launch of a forest of 2-4 trees gives every tree
+    // of a pixel row a wave of its own -- 1024 threads = 16 waves = 16 / T rows of 64 pixels x T trees, the same tile as
+    // four waves x four trees in a lane.  One live 848x480 frame at labels_reduce 2 (T4/D20): 31 -> 20 us; a dense one
+    // 37 -> 35 us.  Only for label maps of up to 128 K pixels: a launch needs 16 waves per tile where it needed 4, and
+    // a dense 848x480 frame at full resolution (1 680 tiles on 512 workgroup slots) takes 95 instead of 82 us, a live one
+    // 42 instead of 48.  Layered runs keep their own one-launch path (two layers' tiles do not fit the chip's wave slots
+    // at 16 waves each: the per-hand graph stayed at 88 us).
+    const int want_tw = g_tree_waves >= 0 ? g_tree_waves : env_int("RDF_TREE_WAVES", 1);
+    const bool tw = allow_tw && want_tw != 0 && !big && !stats && packed && filter_class == -1 && block == 256 && n_trees >= 2 && n_trees <= 4 &&
+                    max_depth >= 1 && sched_mode() != 2 && (long long)n_img * a.Wl * a.Hl <= 131072;
+    if (tw) { rpw = 1; block = 1024; a.check_empty = 1; }
     a.rows_per_wave = rpw;
-    const uint32_t tile_rows = (uint32_t)(block / 64) * (uint32_t)rpw;
+    const uint32_t tile_rows = tw ? (uint32_t)(16 / n_trees) : (uint32_t)(block / 64) * (uint32_t)rpw;
     a.tiles_y = ((uint32_t)a.Hl + tile_rows - 1u) / tile_rows;
     const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
 
     // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B][pixel list] ----
-    const long long budget = lds_budget(block);
+    const long long budget = lds_budget(tw ? 256 : block);
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
     const bool compact_launch = (block == 256 || block == 512) && !stats && filter_class != -1 && g_compaction != 0;
     // Halo and the levels that must stay in LDS, by measurement (profiles/r02_sweep_*.txt).  256-thread workgroups (32.7 KB):
@@ -1207,7 +1271,9 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // (Throughput shape only: for a single small frame staging a narrow tile cost more than it saved, 91 vs 87 us.)
     const int h_min = big ? 0 : halo;
     // pixel list: one uint16 per tile pixel, then one uint32 per tile row
-    const long long list_bytes = compact_launch ? (((long long)block * rpw * 2 + (long long)tile_rows * 4) + 15) & ~15ll : 0;
+    // (tree waves use the list region for the words the trees of a row exchange: tile_rows x T x 64)
+    const long long list_bytes = tw ? (long long)tile_rows * n_trees * 256 :
+                                 compact_launch ? (((long long)block * rpw * 2 + (long long)tile_rows * 4) + 15) & ~15ll : 0;
     // levels of the forest the caller pinned into LDS (rdf_set_lds_levels): the tile then gets all that is left of the
     // budget instead of half of it
     int k_forced = g_lds_levels >= 0 ? g_lds_levels : env_int("RDF_LDS_LEVELS", -1);
@@ -1248,12 +1314,14 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     a.lds_tile_off = (uint32_t)(node_bytes + 16);
     a.lds_mail_off = (uint32_t)(node_bytes + 16 + tile_bytes);
     a.lds_list_off = (uint32_t)(node_bytes + 32 + tile_bytes);
+    a.lds_xchg_off = a.lds_list_off;
     const int lds_bytes = (int)(node_bytes + tile_bytes + 32 + list_bytes);
     if (plan_only) {
         plan_only->a = a;
         plan_only->lds_bytes = lds_bytes;
         plan_only->block = block;
         plan_only->big = big;
+        plan_only->tw = tw;
         return RDF_OK;
     }
 
@@ -1261,6 +1329,13 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int cus = usable_cus(st, di.cus);   // a CU-masked stream holds fewer persistent workgroups
+    if (tw) {
+        EvalArgsN<1> ka;
+        ka.l[0] = a;
+        if (a.C <= 4) return launch_multi<4, 1, true>(ka, lds_bytes, cus, st);
+        if (a.C <= 8) return launch_multi<8, 1, true>(ka, lds_bytes, cus, st);
+        return launch_multi<16, 1, true>(ka, lds_bytes, cus, st);
+    }
     if (stats) {
         return packed ? launch_block<true, true>(block, a, lds_bytes, cus, st)
                       : launch_block<false, true>(block, a, lds_bytes, cus, st);
@@ -1390,7 +1465,7 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
             if (!ok) break;
             const int rc = eval_common(depth, 1, dim_x, dim_y, packed[i], forests[i], n_trees[i], max_depth[i], n_classes[i],
                                        nullptr, -1, layer_labels[i], labels_reduce, 1.0f, 0, nullptr, stream,
-                                       /*fill_untouched=*/1, &plans[i]);
+                                       /*fill_untouched=*/1, &plans[i], /*allow_tw=*/false);
             if (rc != RDF_OK) return rc;
             const Plan &pl = plans[i];
             ok = !pl.empty && !pl.big && pl.block == 256 && pl.a.rows_per_wave < kMaxRowsPerWave &&
@@ -1512,6 +1587,7 @@ void rdf_set_halo(int pixels) { g_halo = pixels; }
 void rdf_set_group(int trees) { g_group = trees; }
 void rdf_set_layers_one_launch(int on) { g_layers_one_launch = on; }
 void rdf_set_lds_levels(int levels) { g_lds_levels = levels; }
+void rdf_set_tree_waves(int mode) { g_tree_waves = mode; }
 void rdf_set_stage_vec(int on) { g_stage_vec = on; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }

@@ -281,6 +281,8 @@ void rdf_set_scheduler(int mode);        /* 1 dynamic tile queue (default), 0 st
                                            workgroup (non-persistent), -1 env RDF_SCHED = static | tile */
 void rdf_set_rows_per_wave(int rows);    /* label rows per wave in a tile: 1, 2 or 4; 0 = choose by launch size */
 void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (24) */
+void rdf_set_tree_waves(int mode);     /* small packed launches of 2-4 trees: one wave per tree and pixel row (k_eval_forest<..., TW>);
+                                        * -1 = default (on, or RDF_TREE_WAVES), 0 = off, 1 = on.  Same labels either way. */
 void rdf_set_lds_levels(int levels);     /* top levels of every tree pinned in LDS (the depth tile then gets the rest of
                                             the LDS budget instead of half of it); -1 = fill what the tile leaves */
 void rdf_set_group(int trees);           /* trees a lane walks interleaved: 1..4, 0 = by forest size (256-thread workgroups only) */

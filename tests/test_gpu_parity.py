@@ -416,6 +416,7 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
             lib.rdf_set_rows_per_wave(int(rng.choice([0, 1, 2, 4])))
             lib.rdf_set_scheduler(int(rng.choice([-1, 0, 1, 2])))
             lib.rdf_set_lds_budget_bytes(int(rng.choice([0, 1, 9000, 40000, 120000])))
+            lib.rdf_set_tree_waves(int(rng.choice([-1, -1, 0, 1])))
             want = np.full((n, h // r, w // r), prefill, np.uint16)
             oracle.eval_forest(depth, forest, want, r, filt, 2 if use_filter else None, s)
             for path in ("packed", "direct"):
@@ -430,6 +431,59 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
         lib.rdf_set_rows_per_wave(0)
         lib.rdf_set_scheduler(-1)
         lib.rdf_set_lds_budget_bytes(0)
+        lib.rdf_set_tree_waves(-1)
+
+
+@pytest.mark.parametrize("trees,classes,r,topology", [(4, 4, 2, "full"), (4, 4, 1, "trained"), (3, 9, 2, "trained"), (2, 20, 1, "full"),
+                                                      (4, 3, 3, "trained"), (2, 5, 2, "trained")])
+def test_tree_waves_give_the_oracles_labels(trees, classes, r, topology, rdf, evs, oracle, gpu_runtime):
+    """Small packed launches of 2-4 trees run one WAVE per tree and pixel row and meet in LDS (k_eval_forest<..., TW>;
+    rdf_set_tree_waves, default on).  The same labels as the oracle and as the four-trees-in-a-lane kernel: live and dense
+    frames, odd frame sizes (partial tiles, idle waves for three trees), class counts beyond one register chunk, pixels
+    that reach no leaf (pre-fill kept), every pre-fill value, and a launch replayed from a captured graph."""
+    import torch
+    lib = gpu_runtime.lib
+    synth = rdf.synth
+    forest = synth.forest(trees, 11, classes, topology, first_tree=300 + trees)
+    if topology == "trained":
+        forest[:, -(forest.shape[1] + 1) // 2:, 5:7] = -1.0        # last level says "continue": those pixels get no label
+    for n, h, w, kinds in ((1, 240, 424, ["live"]), (1, 97, 131, ["dense"]), (2, 64, 200, ["dense", "live"])):
+        depth = synth.frames(kinds, 5100 + h, h, w)
+        depth[::7, ::5] = 0
+        for prefill in (65535, 0):
+            want = np.full((n, h // r, w // r), prefill, np.uint16)
+            oracle.eval_forest(depth, forest, want, r, None, None, 1.0)
+            got = {}
+            try:
+                for mode in (1, 0):
+                    lib.rdf_set_tree_waves(mode)
+                    got[mode] = _gpu_forest(rdf, evs["packed"], depth, forest, prefill, r, None, None, 1.0)
+            finally:
+                lib.rdf_set_tree_waves(-1)
+            assert np.array_equal(got[1], want), (trees, classes, r, topology, h, w, prefill, "tree waves")
+            assert np.array_equal(got[0], want), (trees, classes, r, topology, h, w, prefill, "trees in a lane")
+    # replayed from a graph, on changing frames
+    F = rdf.DecisionForest.from_numpy(forest)
+    F.packed(1.0)
+    d_dev = rdf.to_device(synth.frames(["live"], 5300, 240, 424))
+    out = rdf.DeviceArray((1, 240 // r, 424 // r), np.uint16)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out.fill(65535)
+        evs["packed"].get_labels_forest(F, d_dev, out, labels_reduce=r)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        out.fill(65535)
+        evs["packed"].get_labels_forest(F, d_dev, out, labels_reduce=r)
+    for it in range(3):
+        frame = synth.frames(["live" if it % 2 else "dense"], 5400 + it, 240, 424)
+        d_dev.set(frame)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = np.full((1, 240 // r, 424 // r), 65535, np.uint16)
+        oracle.eval_forest(frame, forest, want, r, None, None, 1.0)
+        assert np.array_equal(out.get(), want), it
 
 
 def test_two_streams_do_not_share_queue_state(rdf, evs, oracle, gpu_runtime):
