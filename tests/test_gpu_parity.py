@@ -718,13 +718,13 @@ def test_captured_launch_has_its_own_queue_slot_and_replays_next_to_direct_launc
         assert np.array_equal(Lb.get(), wb), it
 
 
-@pytest.mark.parametrize("one_launch", [1, 0])
-def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, rdf, gpu_runtime, oracle):
+@pytest.mark.parametrize("one_launch,tree_waves", [(1, 1), (1, 0), (0, 1)])
+def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, tree_waves, rdf, gpu_runtime, oracle):
     """A single-frame run of a packed stack evaluates its layers unfiltered in ONE launch (workgroup b takes layer b % n) and
     filters in the composite kernel (rdf_set_layers_one_launch, default on for small launches); with it off the layers run
     one after the other, filtered.  Same per-layer label images and composite either way: the oracle's chain -- on
     changing frames, replayed from a captured graph, and with a layer whose filter class no pixel has (layers 1 and 2
-    then come out all-65535)."""
+    then come out all-65535).  The tree-waves knob (single small forests only) must not change anything here."""
     import torch
     synth = rdf.synth
     lib = gpu_runtime.lib
@@ -736,6 +736,7 @@ def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, rdf, gpu_r
                       {"model": rdf.DecisionForest.from_numpy(forests[2]), "filter_model": 1, "filter_model_class": 2}],
            "conditions": conditions, "label_colors": [[i, i, i, 255] for i in range(10)]}
     lib.rdf_set_layers_one_launch(one_launch)
+    lib.rdf_set_tree_waves(tree_waves)
     try:
         lf = rdf.LayeredDecisionForest(cfg, (h, w), r)
         dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
@@ -786,6 +787,7 @@ def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, rdf, gpu_r
     finally:
         torch.cuda.synchronize()
         lib.rdf_set_layers_one_launch(-1)
+        lib.rdf_set_tree_waves(-1)
 
 
 def test_layered_fuzz_against_oracle(rdf, gpu_runtime, oracle):
@@ -809,6 +811,8 @@ def test_layered_fuzz_against_oracle(rdf, gpu_runtime, oracle):
             forests, layers, n_classes = [], [], []
             for i in range(n_layers):
                 T, D, C = int(rng.integers(1, 10)), int(rng.integers(1, 12)), int(rng.integers(1, 19))
+                if it % 2:
+                    T = int(rng.integers(2, 5))       # the forest sizes tree waves take when a layer runs on its own
                 f = rdf.synth.forest(T, D, C, str(rng.choice(["full", "trained"])), first_tree=1000 + 10 * it + i)
                 forests.append(f)
                 n_classes.append(C)
@@ -851,8 +855,9 @@ def test_layered_fuzz_against_oracle(rdf, gpu_runtime, oracle):
             oracle.composite([x[0] for x in want], np.array(cond, np.int32), comp)
             dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
             dbuf.cu().set(frame)
-            for route in ("one launch", "filtered launches", "step by step"):
+            for route in ("one launch", "one launch, trees in a lane", "filtered launches", "step by step"):
                 lib.rdf_set_layers_one_launch(0 if route == "filtered launches" else -1)
+                lib.rdf_set_tree_waves(0 if route == "one launch, trees in a lane" else -1)
                 lf = rdf.LayeredDecisionForest(cfg, (h, w), r, fused=route != "step by step")
                 lbuf.cu().fill(3)
                 lf.run(dbuf, lbuf, s)
@@ -862,6 +867,7 @@ def test_layered_fuzz_against_oracle(rdf, gpu_runtime, oracle):
                 assert np.array_equal(lbuf.cu().get(), comp[0]), f"iteration {it}, {route}: composite"
     finally:
         lib.rdf_set_layers_one_launch(-1)
+        lib.rdf_set_tree_waves(-1)
 
 
 @pytest.mark.parametrize("r,s", [(1, 1.0), (3, 0.5)])
