@@ -58,7 +58,8 @@ constexpr uint32_t kFlagLeftLeaf = 1u, kFlagRightLeaf = 2u, kFlagExact = 4u;
 constexpr int kSchedSlots = 128;        // one per (device, stream) that launches directly
 constexpr int kGraphSlots = 384;        // one per launch recorded into a hipGraph (stream capture)
 
-// Dynamic tile queue state: {next tile, workgroups finished}.  One slot per (device, stream) that launches directly
+// Dynamic tile queue state.  A workgroup's first tile is its own index; the queues hand out the tiles beyond the grid size
+// (a launch with no more tiles than workgroups never touches its slot).  One slot per (device, stream) that launches directly
 // (launches on one stream run in order, so they never meet in a slot) and a slot of its own for every launch recorded
 // into a hipGraph: a graph replays on whatever stream it is launched on, so its launch must not share the slot of the
 // stream it happened to be captured on (an executable graph never runs concurrently with itself).
