@@ -34,6 +34,9 @@ SIGNATURES = {
     "rdf_mean_shift": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_fingertip_heights": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                                        _c_float, _c_float, _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_mean_shift_heights": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
+                                        _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_void_p,
+                                        _c_void_p, _c_void_p]),
     "rdf_convert_0s_to_maxuint": (_c_int, [_c_void_p, _c_size_t, _c_void_p]),
     "rdf_setup_depth_image_for_forest": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "rdf_stencil_depth_image_by_group": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),

@@ -73,8 +73,37 @@ __device__ __forceinline__ void block_sum3(double a, double b, double c, double 
 // taken in a fixed order (thread-strided partial sums, shuffle tree, waves in order): bitwise reproducible.
 // An earlier version ran one launch per round over 64 workgroups with a cross-workgroup partial-sum hand-off at every
 // kernel boundary: 7 launches, 74 us for the app's 424x240 label map (profiles/r02_pipeline_kernel_stats_before.csv).
+struct HeightArgs {
+    const int *class_ids;      // 1-based labels (device); n_ids of them
+    int n_ids;
+    const uint16_t *depth;     // the ORIGINAL depth frame (3d_bz.py:515)
+    int dim_x, dim_y, labels_reduce;
+    float fx, fy, ppx, ppy;
+    const float *plane;        // 4x4 row-major (device)
+    double *heights;           // [n_ids]
+};
+
+__device__ __forceinline__ double height_of_mode(double mx, double my, const HeightArgs &h)
+{
+    double out = nan("");
+    if (mx == mx && my == my && fabs(mx) < 1e9 && fabs(my) < 1e9) {
+        const long long px = (long long)mx * h.labels_reduce, py = (long long)my * h.labels_reduce;   // trunc toward 0
+        if (px >= 0 && py >= 0 && px < h.dim_x && py < h.dim_y) {
+            const float z = (float)h.depth[py * h.dim_x + px];
+            const float x = ((float)px - h.ppx) / h.fx, y = ((float)py - h.ppy) / h.fy;
+            const double pt[4] = {(double)(z * x), (double)(z * y), (double)z, 1.0};
+            double pz = 0.0;
+            for (int k = 0; k < 4; ++k) pz += (double)h.plane[2 * 4 + k] * pt[k];
+            out = -pz;
+        }
+    }
+    return out;
+}
+
+template <bool HEIGHTS>
 __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t *labels, int dim_x, int dim_y, int L,
-                                                                 const float *variances, int num_rounds, double *means_out)
+                                                                 const float *variances, int num_rounds, double *means_out,
+                                                                 const HeightArgs hp)
 {
     extern __shared__ uint32_t s_list[];
     __shared__ double s_tab[kMsTabCap];      // round's weights by column, then by row (see the rounds below)
@@ -239,35 +268,27 @@ __global__ __launch_bounds__(kMsThreads) void k_mean_shift_fused(const uint16_t 
         my = my + tot[1] / tot[2];
     }
     if (tid == 0) { means_out[blockIdx.x * 2] = mx; means_out[blockIdx.x * 2 + 1] = my; }
+    if (HEIGHTS) {
+        // the heights of this class's fingertips ride on its workgroup (rdf_mean_shift_heights: one launch less per hand
+        // and frame); ids that name no class are the first workgroup's
+        if (tid < hp.n_ids) {
+            const int c = hp.class_ids[tid];
+            if (c == (int)want) hp.heights[tid] = height_of_mode(mx, my, hp);
+            else if (blockIdx.x == 0 && (c < 1 || c > L)) hp.heights[tid] = nan("");
+        }
+    }
 }
 
 // Heights of the requested classes' modes above the calibrated plane (3d_bz.py:503-522):
 //   px,py = int(mean) * labels_reduce; off-frame -> NaN ("reset"); z = depth[py][px];
 //   pt = z * ((px-ppx)/fx, (py-ppy)/fy, 1)  (librealsense rs2_deproject_pixel_to_point, no distortion, fp32);
 //   height = -(plane @ [pt,1]).z  with the fp32 plane matrix promoted to fp64 like numpy's float32 @ float64.
-__global__ void k_fingertip_heights(const double *means, int L, const int *class_ids, int n_ids, const uint16_t *depth,
-                                    int dim_x, int dim_y, int labels_reduce, float fx, float fy, float ppx, float ppy,
-                                    const float *plane, double *heights)
+__global__ void k_fingertip_heights(const double *means, int L, const HeightArgs h)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_ids) return;
-    const int c = class_ids[i];
-    double out = nan("");
-    if (c >= 1 && c <= L) {
-        const double mx = means[(c - 1) * 2], my = means[(c - 1) * 2 + 1];
-        if (mx == mx && my == my && fabs(mx) < 1e9 && fabs(my) < 1e9) {
-            const long long px = (long long)mx * labels_reduce, py = (long long)my * labels_reduce;   // trunc toward 0
-            if (px >= 0 && py >= 0 && px < dim_x && py < dim_y) {
-                const float z = (float)depth[py * dim_x + px];
-                const float x = ((float)px - ppx) / fx, y = ((float)py - ppy) / fy;
-                const double pt[4] = {(double)(z * x), (double)(z * y), (double)z, 1.0};
-                double pz = 0.0;
-                for (int k = 0; k < 4; ++k) pz += (double)plane[2 * 4 + k] * pt[k];
-                out = -pz;
-            }
-        }
-    }
-    heights[i] = out;
+    if (i >= h.n_ids) return;
+    const int c = h.class_ids[i];
+    h.heights[i] = (c >= 1 && c <= L) ? height_of_mode(means[(c - 1) * 2], means[(c - 1) * 2 + 1], h) : nan("");
 }
 
 } // namespace
@@ -280,10 +301,9 @@ size_t rdf_mean_shift_workspace_bytes(int num_classes, int num_rounds)
     return 0;      // every class iterates inside one workgroup: nothing is handed between workgroups any more
 }
 
-int rdf_mean_shift(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,
-                   int num_rounds, double *means_out, void *workspace, void *stream)
+static int mean_shift_launch(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,
+                             int num_rounds, double *means_out, const HeightArgs *heights, void *stream)
 {
-    (void)workspace;
     if (dim_x < 0 || dim_y < 0 || dim_x > 65535 || dim_y > 65535 || num_classes < 0 || num_classes > kMsMaxClasses ||
         num_rounds < 0)
         return RDF_ERR_BAD_ARG;
@@ -291,23 +311,37 @@ int rdf_mean_shift(const uint16_t *labels, int dim_x, int dim_y, int num_classes
     if ((long long)dim_x * dim_y >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     if (!means_out || (num_rounds > 0 && (!labels || !variances))) return RDF_ERR_NULL_PTR;
     const int lds_bytes = (int)(kMsListCap * sizeof(uint32_t));
-    {   // more than 64 KB of dynamic LDS has to be allowed once per device
+    const void *kp = heights ? reinterpret_cast<const void *>(k_mean_shift_fused<true>)
+                             : reinterpret_cast<const void *>(k_mean_shift_fused<false>);
+    {   // more than 64 KB of dynamic LDS has to be allowed once per device and kernel
         static std::mutex mu;
-        static unsigned long long allowed = 0ull;
+        static unsigned long long allowed[2] = {0ull, 0ull};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
         std::lock_guard<std::mutex> lock(mu);
-        if (dev >= 64 || !((allowed >> dev) & 1ull)) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mean_shift_fused),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        unsigned long long &bits = allowed[heights ? 1 : 0];
+        if (dev >= 64 || !((bits >> dev) & 1ull)) {
+            const hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) return (int)e;
-            if (dev < 64) allowed |= 1ull << dev;
+            if (dev < 64) bits |= 1ull << dev;
         }
     }
-    hipLaunchKernelGGL(k_mean_shift_fused, dim3((unsigned)num_classes), dim3(kMsThreads), lds_bytes,
-                       reinterpret_cast<hipStream_t>(stream), labels, dim_x, dim_y, num_classes, variances, num_rounds,
-                       means_out);
+    if (heights)
+        hipLaunchKernelGGL(k_mean_shift_fused<true>, dim3((unsigned)num_classes), dim3(kMsThreads), lds_bytes,
+                           reinterpret_cast<hipStream_t>(stream), labels, dim_x, dim_y, num_classes, variances, num_rounds,
+                           means_out, *heights);
+    else
+        hipLaunchKernelGGL(k_mean_shift_fused<false>, dim3((unsigned)num_classes), dim3(kMsThreads), lds_bytes,
+                           reinterpret_cast<hipStream_t>(stream), labels, dim_x, dim_y, num_classes, variances, num_rounds,
+                           means_out, HeightArgs{});
     return (int)hipGetLastError();
+}
+
+int rdf_mean_shift(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,
+                   int num_rounds, double *means_out, void *workspace, void *stream)
+{
+    (void)workspace;
+    return mean_shift_launch(labels, dim_x, dim_y, num_classes, variances, num_rounds, means_out, nullptr, stream);
 }
 
 int rdf_fingertip_heights(const double *means, int num_classes, const int *class_ids, int n_ids,
@@ -317,10 +351,29 @@ int rdf_fingertip_heights(const double *means, int num_classes, const int *class
     if (num_classes < 0 || n_ids < 0 || dim_x < 0 || dim_y < 0 || labels_reduce < 1) return RDF_ERR_BAD_ARG;
     if (n_ids == 0) return RDF_OK;
     if (!means || !class_ids || !depth || !plane || !heights_out) return RDF_ERR_NULL_PTR;
+    const HeightArgs h = {class_ids, n_ids, depth, dim_x, dim_y, labels_reduce, fx, fy, ppx, ppy, plane, heights_out};
     hipLaunchKernelGGL(k_fingertip_heights, dim3((n_ids + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
-                       means, num_classes, class_ids, n_ids, depth, dim_x, dim_y, labels_reduce, fx, fy, ppx, ppy, plane,
-                       heights_out);
+                       means, num_classes, h);
     return (int)hipGetLastError();
+}
+
+int rdf_mean_shift_heights(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,
+                           int num_rounds, double *means_out, const int *class_ids, int n_ids, const uint16_t *depth,
+                           int depth_dim_x, int depth_dim_y, int labels_reduce, float fx, float fy, float ppx, float ppy,
+                           const float *plane, double *heights_out, void *stream)
+{
+    if (n_ids < 0 || n_ids > kMsThreads || depth_dim_x < 0 || depth_dim_y < 0 || labels_reduce < 1) return RDF_ERR_BAD_ARG;
+    if (n_ids == 0 || num_classes == 0) {
+        // nothing to fuse: the two calls, one of which does nothing (no class at all: every id is "reset")
+        int rc = mean_shift_launch(labels, dim_x, dim_y, num_classes, variances, num_rounds, means_out, nullptr, stream);
+        if (rc != RDF_OK || n_ids == 0) return rc;
+        return rdf_fingertip_heights(means_out, num_classes, class_ids, n_ids, depth, depth_dim_x, depth_dim_y,
+                                     labels_reduce, fx, fy, ppx, ppy, plane, heights_out, stream);
+    }
+    if (!class_ids || !depth || !plane || !heights_out) return RDF_ERR_NULL_PTR;
+    const HeightArgs h = {class_ids, n_ids, depth, depth_dim_x, depth_dim_y, labels_reduce, fx, fy, ppx, ppy, plane,
+                          heights_out};
+    return mean_shift_launch(labels, dim_x, dim_y, num_classes, variances, num_rounds, means_out, &h, stream);
 }
 
 } // extern "C"

@@ -42,6 +42,22 @@ class MeanShift:
     def run(self, num_rounds, labels, num_labels, variances):
         return self.run_device(num_rounds, labels, num_labels, variances).get()
 
+    def run_device_with_heights(self, num_rounds, labels, num_labels, variances, class_ids, n_ids, depth_image,
+                                labels_reduce, intrinsics, plane, means_out_ptr, heights_out_ptr):
+        """run_device() and fingertip_heights() in ONE launch (rdf_mean_shift_heights): the same means and heights, bit for
+        bit.  class_ids int32 [n_ids] and plane float32 [4,4] on the device; the two outputs are raw device-accessible
+        pointers (float64 [num_labels, 2] and [n_ids]) -- HandPipeline hands in pinned host memory, so that the frame's
+        result needs no copy."""
+        dim_y, dim_x = labels.shape[-2:]
+        ddy, ddx = depth_image.shape[-2:]
+        fx, fy, ppx, ppy = (float(v) for v in intrinsics)
+        rc = self._lib.rdf_mean_shift_heights(device_ptr(labels), int(dim_x), int(dim_y), int(num_labels),
+                                              device_ptr(variances), int(num_rounds), int(means_out_ptr),
+                                              device_ptr(class_ids), int(n_ids), device_ptr(depth_image), int(ddx), int(ddy),
+                                              int(labels_reduce), fx, fy, ppx, ppy, device_ptr(plane), int(heights_out_ptr),
+                                              self._rt.stream())
+        _lib.check(self._lib, rc, "rdf_mean_shift_heights")
+
 
 def fingertip_heights(means, class_ids, depth_image, labels_reduce, fx, fy, ppx, ppy, plane):
     """Device version of the per-fingertip height of 3d_bz.py:503-522.

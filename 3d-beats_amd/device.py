@@ -37,6 +37,15 @@ class HipRuntime:
     def alloc(self, nbytes):
         return self.torch.empty(max(int(nbytes), 1), dtype=self.torch.uint8, device="cuda")
 
+    def alloc_host_mapped(self, nbytes):
+        """Pinned host memory that kernels can write (hipHostMalloc memory is mapped into the device's address space at
+        the same address on ROCm): (handle, device-accessible pointer, numpy uint8 view), or None if it cannot be had."""
+        try:
+            t = self.torch.empty(max(int(nbytes), 1), dtype=self.torch.uint8).pin_memory()
+            return t, int(t.data_ptr()), t.numpy()
+        except Exception:      # noqa: BLE001
+            return None
+
     def ptr(self, handle):
         return int(handle.data_ptr())
 

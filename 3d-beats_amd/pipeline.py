@@ -57,6 +57,12 @@ class HandPipeline:
         # means [L,2] followed by heights [n_fingertips]: one device->host copy per frame
         self._L = int(layered_rdf.num_layered_classes)
         self._result = DeviceArray((self._L * 2 + len(self.fingertip_idxes),), np.float64)
+        # fused_io: the modes and the heights are ONE launch (rdf_mean_shift_heights) that writes straight into pinned host
+        # memory -- the frame ends with a stream synchronisation instead of a device-to-host copy
+        self._host = None
+        alloc = getattr(self._rt, "alloc_host_mapped", None)
+        if self.fused_io and alloc is not None and len(self.fingertip_idxes) <= 1024:
+            self._host = alloc(self._result.nbytes)
 
     def run(self, depth_image, depth_image_mm_groups, g_id, flip_x):
         """depth_image: GpuBuffer uint16 [DIM_Y, DIM_X] (the frame, 0 = no reading);
@@ -90,7 +96,11 @@ class HandPipeline:
         return replay
 
     def _read(self):
-        out = self._result.get()
+        if self._host is not None:
+            self._rt.synchronize()         # the current stream, as the copy below would be
+            out = self._host[2].view(np.float64).copy()
+        else:
+            out = self._result.get()
         return out[:self._L * 2].reshape(self._L, 2), out[self._L * 2:]
 
     def _enqueue(self, depth_image, depth_image_mm_groups, g_id, flip_x):
@@ -123,6 +133,13 @@ class HandPipeline:
             po.make_rgba_from_labels(np.uint32(self.LABELS_DIM_X), np.uint32(self.LABELS_DIM_Y), np.uint32(self._L),
                                      self.labels_image.cu(), self.layered_rdf.label_colors.cu(), self.labels_image_rgba.cu())
 
+        if self._host is not None:
+            base = self._host[1]
+            self.mean_shift.run_device_with_heights(
+                self.mean_shift_rounds, self.labels_image.cu().reshape((1, self.LABELS_DIM_Y, self.LABELS_DIM_X)), self._L,
+                self.mean_shift_variances, self._ids, len(self.fingertip_idxes), depth_image.cu(), self.LABELS_REDUCE,
+                self.intrinsics, self._plane, base, base + self._L * 2 * 8)
+            return
         means = self.mean_shift.run_device(self.mean_shift_rounds,
                                            self.labels_image.cu().reshape((1, self.LABELS_DIM_Y, self.LABELS_DIM_X)),
                                            self._L, self.mean_shift_variances, out=self._result[:self._L * 2])

@@ -174,6 +174,17 @@ int rdf_fingertip_heights(const double *means, int num_classes, const int *class
                           float ppx, float ppy, const float *plane, double *heights_out, void *stream);
 
 /*
+ * rdf_mean_shift followed by rdf_fingertip_heights in ONE launch: the workgroup that finds a class's mode also writes
+ * the heights of the ids that name that class (ids that name no class: NaN).  Same means and heights, bit for bit, as the
+ * two calls; what the app's per-hand chain uses (src/3d_bz.py:461-465 then :503-522).  n_ids <= 1024.  means_out and
+ * heights_out may be device memory or device-accessible (pinned, mapped) host memory.
+ */
+int rdf_mean_shift_heights(const uint16_t *labels, int dim_x, int dim_y, int num_classes, const float *variances,
+                           int num_rounds, double *means_out, const int *class_ids, int n_ids, const uint16_t *depth,
+                           int depth_dim_x, int depth_dim_y, int labels_reduce, float fx, float fy, float ppx, float ppy,
+                           const float *plane, double *heights_out, void *stream);
+
+/*
  * ---- element-wise kernels either side of the forest; all in place / byte exact ----
  * rdf_convert_0s_to_maxuint           src/cuda/points_ops.cu:117-127   depth[i] == 0 -> 65535
  * rdf_setup_depth_image_for_forest    :149-165   depth[i] == 0 or pts[i].w == 0 -> 65535 (pts = float4 per pixel)

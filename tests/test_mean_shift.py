@@ -104,3 +104,40 @@ def test_mean_shift_class_bigger_than_the_lds_list(rdf, gpu_runtime):
         assert np.isnan(got[2]).all() and np.isnan(want[2]).all()
         assert np.abs(got[:2] - want[:2]).max() < 1e-9, np.abs(got[:2] - want[:2]).max()
         assert np.array_equal(got.view(np.uint64), ms.run(rounds, dl, L, dv).view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_mean_shift_and_heights_in_one_launch_equal_the_two_calls(rdf, gpu_runtime):
+    """rdf_mean_shift_heights (what HandPipeline uses): the same means and the same heights, bit for bit, as rdf_mean_shift
+    followed by rdf_fingertip_heights -- with ids that name no class (0, L + 1), an id whose class has no pixel (NaN mode),
+    repeated ids, outputs in device memory and in pinned host memory the kernel writes directly."""
+    import torch
+    msmod = importlib.import_module("3d-beats_amd.cuda.mean_shift")
+    ms = msmod.MeanShift()
+    h, w, L, r = 240, 424, 6, 2
+    lab = _label_map(23, h, w, L, absent=(4,))
+    depth = rdf.synth.frames(["dense"], 91, h * r, w * r)[0]
+    var = np.full(L, 10.0, np.float32)
+    plane = (np.eye(4) + 0.1 * np.random.default_rng(5).standard_normal((4, 4))).astype(np.float32)
+    ids = np.array([1, 6, 4, 0, 7, 2, 2, 5, 3], np.int32)
+    intr = (421.3, 420.9, 423.1, 238.6)
+    dl, dv, dd = rdf.to_device(lab[None]), rdf.to_device(var), rdf.to_device(depth)
+    d_ids, d_plane = rdf.to_device(ids), rdf.to_device(plane)
+    for rounds in (1, 6):
+        means = ms.run_device(rounds, dl, L, dv)
+        want_m = means.get()
+        want_h = msmod.fingertip_heights(means, [int(i) for i in ids], dd, r, *intr, plane)
+        # device outputs
+        out = rdf.DeviceArray((2 * L + len(ids),), np.float64).fill(7.0)
+        ms.run_device_with_heights(rounds, dl, L, dv, d_ids, len(ids), dd, r, intr, d_plane, out.ptr, out.ptr + 16 * L)
+        got = out.get()
+        assert np.array_equal(got[:2 * L].view(np.uint64), want_m.reshape(-1).view(np.uint64))
+        assert np.array_equal(got[2 * L:].view(np.uint64), np.asarray(want_h).view(np.uint64)), (got[2 * L:], want_h)
+        assert np.isnan(want_h[[2, 3, 4]]).all() and not np.isnan(want_h[[0, 1, 5, 6, 7, 8]]).any()
+        # pinned host outputs, written by the kernel
+        host = gpu_runtime.alloc_host_mapped((2 * L + len(ids)) * 8)
+        assert host is not None
+        host[2].view(np.float64)[:] = 7.0
+        ms.run_device_with_heights(rounds, dl, L, dv, d_ids, len(ids), dd, r, intr, d_plane, host[1], host[1] + 16 * L)
+        torch.cuda.synchronize()
+        assert np.array_equal(host[2].view(np.float64).view(np.uint64), got.view(np.uint64))
