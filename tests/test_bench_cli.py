@@ -61,3 +61,23 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
     # config 5's workload sharded over the same ranks (1280x720 dense frames; the forest shrunk for the test)
     c5 = d["cfg5_all_ranks"]
     assert c5["n_gpus"] == 2 and c5["gather_check"] == "ok" and c5["value"] > 0 and c5["value_kernel_only"] >= c5["value"]
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_one_gpu(tmp_path):
+    """The same rehearsal with four ranks (rank-indexed buffers, checksums and the config-5 leg beyond world size 2; four
+    processes on the card stay inside the box's limit of six)."""
+    env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--frames", "3", "--depth", "11", "--backend", "gloo", "--gather", "both", "--reserve-cus", "0",
+           "--cfg5-frames", "1", "--cfg5-trees", "2", "--cfg5-depth", "11"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 4 and d["config"]["gather_check"] == "ok"
+    dd = d["distributed"]
+    assert dd["rccl_ranks"] == 4 and len(dd["devices"]) == 4 and sorted(x["rank"] for x in dd["devices"]) == [0, 1, 2, 3]
+    assert all(m["gather_check"] == "ok" for m in dd["gather_modes"].values()) and len(dd["gather_modes"]) == 2
+    c5 = d["cfg5_all_ranks"]
+    assert c5["n_gpus"] == 4 and c5["gather_check"] == "ok" and "4 x 1 dense" in c5["workload"]
