@@ -1073,7 +1073,7 @@ int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 template <int CMAX, int NL, bool TW = false>
 int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st)
 {
-    constexpr int kBlock = TW ? 1024 : 256;      // tree waves: 16 waves = 16 / T pixel rows x T trees
+    constexpr int kBlock = TW ? 512 : 256;      // tree waves: 8 waves = 8 / T pixel rows x T trees
     auto kern = k_eval_forest<kBlock, true, CMAX, false, false, TW ? 1 : kGroup, false, NL, TW>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0, dev = 0;
@@ -1241,18 +1241,19 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         while (rpw > 1 && (long long)n_img * a.tiles_x * ((a.Hl + rpw - 1) / rpw) < waves_wanted) rpw >>= 1;
     }
     // Tree waves (k_eval_forest<..., TW>): a small unfiltered packed launch of a forest of 2-4 trees gives every tree
-    // of a pixel row a wave of its own -- 1024 threads = 16 waves = 16 / T rows of 64 pixels x T trees, the same tile as
-    // four waves x four trees in a lane.  One live 848x480 frame at labels_reduce 2 (T4/D20): 31 -> 20 us; a dense one
-    // 37 -> 35 us.  Only for label maps of up to 128 K pixels: a launch needs 16 waves per tile where it needed 4, and
-    // a dense 848x480 frame at full resolution (1 680 tiles on 512 workgroup slots) takes 95 instead of 82 us, a live one
-    // 42 instead of 48.  Layered runs keep their own one-launch path (two layers' tiles do not fit the chip's wave slots
-    // at 16 waves each: the per-hand graph stayed at 88 us).
+    // of a pixel row a wave of its own -- 512 threads = 8 waves = 8 / T rows of 64 pixels x T trees (two rows for three or
+    // four trees: half the tile of four waves x four trees in a lane, on twice the CUs).  One live 848x480 frame at
+    // labels_reduce 2 (T4/D20): 31 -> 19 us; a dense one 37 -> 31 us (with 1 024 threads = four rows x four trees: 20 and
+    // 35 us; with 256 = one row: 32 and 44 us, more tiles than workgroup slots).  Only for label maps of up to 128 K pixels:
+    // a tile now needs four times the wave slots, and a dense 848x480 frame at full resolution got slower (82 -> 95 us with
+    // the 1 024-thread shape; live: 48 -> 42).  Layered runs keep their own one-launch path (two layers' tiles do not fit
+    // the chip's wave slots: the per-hand graph stayed at 88 us).
     const int want_tw = g_tree_waves >= 0 ? g_tree_waves : env_int("RDF_TREE_WAVES", 1);
     const bool tw = allow_tw && want_tw != 0 && !big && !stats && packed && filter_class == -1 && block == 256 && n_trees >= 2 && n_trees <= 4 &&
                     max_depth >= 1 && sched_mode() != 2 && (long long)n_img * a.Wl * a.Hl <= 131072;
-    if (tw) { rpw = 1; block = 1024; a.check_empty = 1; }
+    if (tw) { rpw = 1; block = 512; }
     a.rows_per_wave = rpw;
-    const uint32_t tile_rows = tw ? (uint32_t)(16 / n_trees) : (uint32_t)(block / 64) * (uint32_t)rpw;
+    const uint32_t tile_rows = tw ? (uint32_t)(8 / n_trees) : (uint32_t)(block / 64) * (uint32_t)rpw;
     a.tiles_y = ((uint32_t)a.Hl + tile_rows - 1u) / tile_rows;
     const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
