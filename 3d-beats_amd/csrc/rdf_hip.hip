@@ -1246,8 +1246,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // labels_reduce 2 (T4/D20): 31 -> 19 us; a dense one 37 -> 31 us (with 1 024 threads = four rows x four trees: 20 and
     // 35 us; with 256 = one row: 32 and 44 us, more tiles than workgroup slots).  Only for label maps of up to 128 K pixels:
     // a tile now needs four times the wave slots, and a dense 848x480 frame at full resolution got slower (82 -> 95 us with
-    // the 1 024-thread shape; live: 48 -> 42).  Layered runs keep their own one-launch path (two layers' tiles do not fit
-    // the chip's wave slots: the per-hand graph stayed at 88 us).
+    // the 1 024-thread shape; live: 48 -> 42).  The layers of a stack evaluated in one launch (rdf_layered_run) take the
+    // same shape when every layer can.
     const int want_tw = g_tree_waves >= 0 ? g_tree_waves : env_int("RDF_TREE_WAVES", 1);
     const bool tw = allow_tw && want_tw != 0 && !big && !stats && packed && filter_class == -1 && block == 256 && n_trees >= 2 && n_trees <= 4 &&
                     max_depth >= 1 && sched_mode() != 2 && (long long)n_img * a.Wl * a.Hl <= 131072;
@@ -1468,18 +1468,28 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
         Plan plans[3];
         bool ok = true;
         int cmax = 4, lds = 0;
-        for (int i = 0; i < n_layers && ok; ++i) {
-            ok = packed[i] != nullptr && max_depth[i] <= 27 && n_trees[i] > 0 && max_depth[i] > 0;
-            if (!ok) break;
-            const int rc = eval_common(depth, 1, dim_x, dim_y, packed[i], forests[i], n_trees[i], max_depth[i], n_classes[i],
-                                       nullptr, -1, layer_labels[i], labels_reduce, 1.0f, 0, nullptr, stream,
-                                       /*fill_untouched=*/1, &plans[i], /*allow_tw=*/false);
-            if (rc != RDF_OK) return rc;
-            const Plan &pl = plans[i];
-            ok = !pl.empty && !pl.big && pl.block == 256 && pl.a.rows_per_wave < kMaxRowsPerWave &&
-                 pl.a.rows_per_wave == plans[0].a.rows_per_wave && pl.a.n_tiles == plans[0].a.n_tiles;
-            cmax = n_classes[i] > 8 ? 16 : (n_classes[i] > 4 && cmax < 8 ? 8 : cmax);
-            lds = pl.lds_bytes > lds ? pl.lds_bytes : lds;
+        // Every layer as tree waves (512 threads: two pixel rows x T trees a workgroup) or none: planned with them first,
+        // again without if a layer cannot (one tree, more than four, a big label map).  Config 3's frame: 37 -> 31 us.
+        bool tw_all = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            ok = true; cmax = 4; lds = 0;
+            int n_tw = 0;
+            for (int i = 0; i < n_layers && ok; ++i) {
+                ok = packed[i] != nullptr && max_depth[i] <= 27 && n_trees[i] > 0 && max_depth[i] > 0;
+                if (!ok) break;
+                const int rc = eval_common(depth, 1, dim_x, dim_y, packed[i], forests[i], n_trees[i], max_depth[i], n_classes[i],
+                                           nullptr, -1, layer_labels[i], labels_reduce, 1.0f, 0, nullptr, stream,
+                                           /*fill_untouched=*/1, &plans[i], /*allow_tw=*/pass == 0);
+                if (rc != RDF_OK) return rc;
+                const Plan &pl = plans[i];
+                ok = !pl.empty && !pl.big && (pl.block == 256 || pl.tw) && pl.a.rows_per_wave < kMaxRowsPerWave &&
+                     pl.a.rows_per_wave == plans[0].a.rows_per_wave && (pl.tw || pl.a.n_tiles == plans[0].a.n_tiles);
+                n_tw += pl.tw ? 1 : 0;
+                cmax = n_classes[i] > 8 ? 16 : (n_classes[i] > 4 && cmax < 8 ? 8 : cmax);
+                lds = pl.lds_bytes > lds ? pl.lds_bytes : lds;
+            }
+            tw_all = ok && n_tw == n_layers;
+            if (!ok || n_tw == 0 || tw_all) break;
         }
         if (ok) {
             DeviceInfo di;
@@ -1499,13 +1509,21 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
             if (n_layers == 2) {
                 EvalArgsN<2> ka;
                 ka.l[0] = plans[0].a; ka.l[1] = plans[1].a;
-                rc = cmax == 4 ? launch_multi<4, 2>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 2>(ka, lds, cus, st)
-                                                                                  : launch_multi<16, 2>(ka, lds, cus, st);
+                if (tw_all)
+                    rc = cmax == 4 ? launch_multi<4, 2, true>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 2, true>(ka, lds, cus, st)
+                                                                                            : launch_multi<16, 2, true>(ka, lds, cus, st);
+                else
+                    rc = cmax == 4 ? launch_multi<4, 2>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 2>(ka, lds, cus, st)
+                                                                                      : launch_multi<16, 2>(ka, lds, cus, st);
             } else {
                 EvalArgsN<3> ka;
                 ka.l[0] = plans[0].a; ka.l[1] = plans[1].a; ka.l[2] = plans[2].a;
-                rc = cmax == 4 ? launch_multi<4, 3>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 3>(ka, lds, cus, st)
-                                                                                  : launch_multi<16, 3>(ka, lds, cus, st);
+                if (tw_all)
+                    rc = cmax == 4 ? launch_multi<4, 3, true>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 3, true>(ka, lds, cus, st)
+                                                                                            : launch_multi<16, 3, true>(ka, lds, cus, st);
+                else
+                    rc = cmax == 4 ? launch_multi<4, 3>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 3>(ka, lds, cus, st)
+                                                                                      : launch_multi<16, 3>(ka, lds, cus, st);
             }
             if (rc != RDF_OK) return rc;
             spec.n = n_layers;

@@ -724,7 +724,8 @@ def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, tree_waves
     filters in the composite kernel (rdf_set_layers_one_launch, default on for small launches); with it off the layers run
     one after the other, filtered.  Same per-layer label images and composite either way: the oracle's chain -- on
     changing frames, replayed from a captured graph, and with a layer whose filter class no pixel has (layers 1 and 2
-    then come out all-65535).  The tree-waves knob (single small forests only) must not change anything here."""
+    then come out all-65535).  With tree waves on (the default) the one launch runs every tree of a layer in a wave of its own
+    (all three forests have 3-4 trees); off, four trees in a lane."""
     import torch
     synth = rdf.synth
     lib = gpu_runtime.lib
@@ -812,7 +813,7 @@ def test_layered_fuzz_against_oracle(rdf, gpu_runtime, oracle):
             for i in range(n_layers):
                 T, D, C = int(rng.integers(1, 10)), int(rng.integers(1, 12)), int(rng.integers(1, 19))
                 if it % 2:
-                    T = int(rng.integers(2, 5))       # the forest sizes tree waves take when a layer runs on its own
+                    T = int(rng.integers(2, 5))       # stacks whose layers can all run as tree waves
                 f = rdf.synth.forest(T, D, C, str(rng.choice(["full", "trained"])), first_tree=1000 + 10 * it + i)
                 forests.append(f)
                 n_classes.append(C)
