@@ -78,22 +78,26 @@ constexpr uint32_t kXcdQueuesFrom = 64;          // launches with fewer workgrou
 __device__ unsigned int g_sched[kSchedSlots + kGraphSlots][kSchedWords];
 
 // ---- node records --------------------------------------------------------------------------
-// Hot record, 16 bytes, one 128-bit load per node.  Each word carries a numerator in its high 23 bits, a zero
-// guard bit and one byte of unrelated payload:
-//   w0 = floor(s*u.x) << 9 | T[7:0]         T = integer threshold (see thresh_to_int), 24-bit two's complement
-//   w1 = floor(s*u.y) << 9 | T[15:8]
-//   w2 = floor(s*v.x) << 9 | T[23:16]
-//   w3 = floor(s*v.y) << 9 | flags          flags: kFlagLeftLeaf/RightLeaf = that side is a leaf,
-//                                                  kFlagExact = use the exact record
-// The numerator is decoded with ONE instruction, v_cvt_f32_i32 of the whole word = 512*(x + e), 0 <= e <= 1/2: the
-// payload only adds a fraction of a unit, floor((x+e)/d) = floor(x/d) for integers, and the divide works on
-// 512*d (exact scalings of the verified sequence).
-// Why this is enough: for every depth d in [1,65535] and every fp32 a that is +-0 or has a biased exponent in
-// [40,148] (|a| < 2^22), floor(IEEE a/d) == floor(fastdiv(cvt(floor(a) << 9 | p), 512 d)) for every payload p
-// -- checked exhaustively on gfx950 by tools/verify_intoffset.hip, tools/verify_fastdiv.hip and
-// tools/verify_payload.hip (1.2e14, 2.1e14 and 1.4e14 cases, 0 mismatches; logs under profiles/).  Any other
-// numerator (huge, denormal, inf, NaN) flags the node kFlagExact and the kernel takes the IEEE divide on the
-// fp32 values of the exact record.
+// Hot record, 16 bytes, one 128-bit load per node.  Each word carries a numerator in its high 23 bits, a guard
+// bit and one byte of unrelated payload:
+//   w0 = floor(s*u.x) << 9 | g0 << 8 | T[7:0]       T = integer threshold (see thresh_to_int), 24-bit two's complement
+//   w1 = floor(s*u.y) << 9 | g1 << 8 | T[15:8]
+//   w2 = floor(s*v.x) << 9 | g2 << 8 | T[23:16]
+//   w3 = floor(s*v.y) << 9 | g3 << 8 | flags        flags: kFlagLeftLeaf/RightLeaf = that side is a leaf,
+//                                                          kFlagExact = use the exact record
+//   g = NOT bit 7 of the payload byte, so the nine low bits are a value in [128, 383].
+// The numerator is decoded with ONE instruction, v_cvt_f32_i32 of the whole word = 512*(x + e), 1/4 <= e <= 3/4
+// (the payload and the convert's rounding only move e inside that range): for integers x and d, (x + e)/d lies at
+// least 1/(4d) away from the integers on either side of floor(x/d), which is more than the error of ONE multiply by the
+// pixel's refined reciprocal -- so the whole divide-floor-add of decision_tree_common.hpp:15-18 is
+//     t = fma(n, r/512, 1.5*2^23)   in round-toward-minus-infinity mode:   bits(t) - bits(1.5*2^23) = floor(x/d)
+//     coordinate = bits(t) + (pixel coordinate - bits(1.5*2^23))            one v_add_u32
+// (the level loop runs with the wave's fp32 rounding mode set to round-down; everything outside it in round-to-nearest).
+// Checked exhaustively on gfx950 by tools/verify_magic.hip: every x in [-2^21, 2^21) x every payload byte x every
+// depth 1..65535 against integer floor division (logs under profiles/); tools/verify_intoffset.hip and
+// tools/verify_fastdiv.hip tie integer floor division to the reference's floor(IEEE (s*u)/d) for every fp32 numerator
+// that is +-0 or has a biased exponent in [40,147] (|a| < 2^21).  Any other numerator (huge, denormal, inf, NaN) flags
+// the node kFlagExact and the kernel takes the IEEE divide on the fp32 values of the exact record.
 struct alignas(16) NodeRec16 {
     uint32_t w[4];
 };
@@ -129,7 +133,7 @@ struct EvalArgs {
     uint32_t stage_tw8;    // > 0: stage with 16-byte loads, tw / 8 vectors per row (W, tx0 and twp are multiples of 8)
     uint32_t stage_magic;  // floor(2^32 / stage_tw8) + 1: i / stage_tw8 == umulhi(i, magic) for i < 2^32 / stage_tw8
     uint32_t lds_xchg_off; // (tree waves) where the trees of a pixel row meet
-    uint32_t lds_tile_off; // byte offsets inside the dynamic LDS allocation
+    uint32_t lds_nodes_off; // byte offsets inside the dynamic LDS allocation (the depth tile is at 0)
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
@@ -148,11 +152,17 @@ __device__ __forceinline__ uint32_t child_flags(float l, float r)
     return ((l >= -1.0f && l < 0.0f) ? 0u : kFlagLeftLeaf) | ((r >= -1.0f && r < 0.0f) ? 0u : kFlagRightLeaf);
 }
 
-// Numerators the integer record represents exactly (see NodeRec16): +-0, or biased exponent 40..148.
+// Numerators the integer record represents exactly (see NodeRec16): +-0, or biased exponent 40..147 (|a| < 2^21).
 __device__ __forceinline__ bool int_offset_ok(float a)
 {
     const uint32_t b = __float_as_uint(a);
-    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 108u;
+    return (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 107u;
+}
+
+// payload byte -> the nine low bits of a record word: bit 8 = NOT bit 7 (a value in [128, 383], see NodeRec16)
+__device__ __forceinline__ uint32_t guarded_payload(uint32_t byte)
+{
+    return (byte & 0xFFu) | ((~byte & 0x80u) << 1);
 }
 
 // f = depth[u] - depth[v] is an integer in [-65535, 65535], so `f < thresh` (tree_eval.cu:107)
@@ -178,10 +188,10 @@ __device__ __forceinline__ NodeRec16 encode_node(float sux, float suy, float svx
     }
     const uint32_t t = (uint32_t)thresh_to_int(thresh);   // two's complement, |T| <= 65536
     NodeRec16 r;
-    r.w[0] = ((uint32_t)nx << 9) | (t & 0xFFu);
-    r.w[1] = ((uint32_t)ny << 9) | ((t >> 8) & 0xFFu);
-    r.w[2] = ((uint32_t)mx << 9) | ((t >> 16) & 0xFFu);
-    r.w[3] = ((uint32_t)my << 9) | flags;
+    r.w[0] = ((uint32_t)nx << 9) | guarded_payload(t);
+    r.w[1] = ((uint32_t)ny << 9) | guarded_payload(t >> 8);
+    r.w[2] = ((uint32_t)mx << 9) | guarded_payload(t >> 16);
+    r.w[3] = ((uint32_t)my << 9) | guarded_payload(flags);
     return r;
 }
 
@@ -196,11 +206,14 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
 
 constexpr float kNumScale = 512.0f;   // a decoded numerator is 512 * (x + e), see NodeRec16
+constexpr float kMagic = 12582912.0f;          // 1.5 * 2^23: an fp32 in [2^23, 2^24) counts in units of one
+constexpr uint32_t kMagicBits = 0x4B400000u;   // its bit pattern
 
 struct Node {
     float ax, ay, bx, by;   // numerators of the u and v offsets: kNumScale * (integer + e) from a hot record,
                             // the fp32 values s*u, s*v themselves on a kFlagExact node
-    int t;                  // integer threshold
+    uint32_t lo16;          // T[15:0], T = integer threshold
+    uint32_t w2;            // byte 0 = T[23:16] (two's complement: -1, 0 or 1); the bits above are not defined
     uint32_t flags;         // low 3 bits; the bits above are not defined
 };
 
@@ -211,12 +224,100 @@ __device__ __forceinline__ Node decode_node(const uint4 w)
     n.ay = (float)(int)w.y;
     n.bx = (float)(int)w.z;
     n.by = (float)(int)w.w;
-    // T = {w0.b0, w1.b0, w2.b0} in two byte permutes (v_perm_b32: selectors 0-3 pick bytes of the second
-    // operand, 4-7 of the first, 12 is 0x00), then sign-extended from 24 bits
-    const uint32_t lo = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0400u);
-    n.t = (int)(__builtin_amdgcn_perm(w.z, lo, 0x0c040100u) << 8) >> 8;
+    // T[15:0] = {w1.b0, w0.b0} in one byte permute (v_perm_b32: selectors 0-3 pick bytes of the second operand, 4-7 of
+    // the first, 12 is 0x00); T[23:16] stays where it is and is read in place by the decision's compare (walk_step)
+    n.lo16 = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0400u);
+    n.w2 = w.z;
     n.flags = w.w;
     return n;
+}
+
+// The same three fields from an integer threshold (nodes read from the reference's records).
+__device__ __forceinline__ void set_threshold(Node &n, int t)
+{
+    n.lo16 = (uint32_t)t & 0xFFFFu;
+    n.w2 = (uint32_t)t >> 16;
+}
+
+// One step of the walk (tree_eval.cu:107-121).  g = depth[u] - depth[v] - T[15:0]; the feature is below the threshold
+// iff g < T[23:16] * 65536 iff (g >> 16) < T[23:16] -- one SDWA compare that sign-extends the high word of g and byte 0
+// of w2 in place.  side = 0 (left) when below, else 1; next = 2 h + side by an add with carry-in; the leaf flag of that
+// side (flags bit `side`) is shifted to bit 31 and or-ed in.  Result: the next 1-based heap index while walking,
+// 0x80000000 | (2 h + side) once a leaf is reached.
+__device__ __forceinline__ uint32_t walk_step(uint32_t h, int g, uint32_t w2, uint32_t flags)
+{
+    uint32_t next, t;
+    asm("v_cmp_ge_i32_sdwa vcc, sext(%2), sext(%3) src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
+        "v_cndmask_b32_e64 %1, 31, 30, vcc\n\t"
+        "v_lshlrev_b32_e32 %1, %1, %4\n\t"
+        "v_addc_co_u32_e32 %0, vcc, %5, %5, vcc\n\t"
+        "v_and_or_b32 %0, %1, %6, %0"
+        : "=&v"(next), "=&v"(t)
+        : "v"(g), "v"(w2), "v"(flags), "v"(h), "s"(0x80000000u)
+        : "vcc");
+    return next;
+}
+
+// The wave's fp32 rounding mode (MODE.FP_ROUND bits 1:0: 0 = to nearest even, 2 = toward minus infinity).  The level
+// loop's divide-and-floor is one fma in round-down mode (NodeRec16); everything else -- the reciprocal's refinement,
+// the IEEE divides of kFlagExact nodes, the sums of leaf PDFs -- needs round-to-nearest.  The operand ties a switch to
+// the arithmetic around it: what produced `dep` runs before the switch, what uses it afterwards runs after.
+template <typename T>
+__device__ __forceinline__ void set_round_down(T &dep)
+{
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\ts_nop 0" : "+v"(dep));
+}
+template <typename T>
+__device__ __forceinline__ void set_round_nearest(T &dep)
+{
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 0" : "+v"(dep));
+}
+template <typename T>
+__device__ __forceinline__ void pin(T &v)   // v is computed before this point and used only after it
+{
+    asm volatile("" : "+v"(v));
+}
+
+// A depth probe is answered by the staged LDS tile when it falls inside it (cells outside the image hold 65535 there),
+// else by global memory with the per-axis bounds check of cu_utils.hpp:79-86; a probe outside the image is 65535.
+// Coordinates are RELATIVE TO THE STAGED TILE, x doubled (a byte offset): cx2 = 2 (x - tx0), cy = y - ty0.  The loads
+// are only ISSUED here; their values are consumed after all probes of the level have been issued, so every probe of a
+// level is in flight together and nothing waits inside a divergent branch.  A lane outside the tile reads LDS at an
+// address that means nothing (inside the allocation: some cell; beyond it: the hardware returns 0) and discards it.
+// `img_b` is the wave-uniform base of the current image (a scalar register pair), so a far probe's address is one 32-bit
+// byte offset (a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is < 2^24 when used).
+struct TileCtx {
+    const char *img_b;
+    uint32_t tw2, th, twp2;  // staged tile: 2 x width, height, row pitch in bytes (0, 0, 0: no staged tile)
+    uint32_t W2, H;          // image: 2 x width, height
+    uint32_t tx0_2, ty0;     // image position of the tile's first cell (x doubled), two's complement
+};
+
+struct TileProbe {
+    uint32_t lds_v, glb_v;
+    bool in_tile;
+};
+
+__device__ __forceinline__ TileProbe tprobe_issue(const TileCtx &c, uint32_t cx2, uint32_t cy)
+{
+    TileProbe p;
+    p.in_tile = cx2 < c.tw2 && cy < c.th;
+    // the tile starts at LDS address 0 (the kernel has no static LDS; the launcher checks): byte offset = address
+    p.lds_v = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)(__umul24(cy, c.twp2) + cx2);
+    asm("" : "=v"(p.glb_v));   // only read where in_tile is false
+    if (!p.in_tile) {
+        const uint32_t x2 = cx2 + c.tx0_2, y = cy + c.ty0;
+        p.glb_v = kNoPixel;
+        if (x2 < c.W2 && y < c.H)   // only far lanes touch global memory; the value is consumed after the branch
+            p.glb_v = *reinterpret_cast<const uint16_t *>(c.img_b + (__umul24(y, c.W2) + x2));
+    }
+    return p;
+}
+
+__device__ __forceinline__ int tprobe_value(const TileProbe &p)
+{
+    const uint32_t g = p.glb_v, l = p.lds_v;
+    return (int)(p.in_tile ? l : g);
 }
 
 // FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
@@ -238,8 +339,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
     const uint32_t block_id = NL > 1 ? blockIdx.x / NL : blockIdx.x, n_blocks = NL > 1 ? gridDim.x / NL : gridDim.x;
     const EvalArgs &a = ka.l[role];
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    uint4 *lds_nodes = reinterpret_cast<uint4 *>(lds_raw);
-    uint16_t *lds_tile = reinterpret_cast<uint16_t *>(lds_raw + a.lds_tile_off);
+    // the depth tile sits at LDS address 0, so that a probe's byte offset inside the tile IS its LDS address
+    uint16_t *lds_tile = reinterpret_cast<uint16_t *>(lds_raw);
+    uint4 *lds_nodes = reinterpret_cast<uint4 *>(lds_raw + a.lds_nodes_off);
     uint32_t *s_tile = reinterpret_cast<uint32_t *>(lds_raw + a.lds_mail_off);
     uint16_t *px_list = reinterpret_cast<uint16_t *>(lds_raw + a.lds_list_off);   // the tile's pixels to evaluate, compacted
 
@@ -272,9 +374,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
             lds_nodes[i] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
         }
     }
-    if (tid == 0) lds_tile[-1] = (uint16_t)kNoPixel;   // what a probe outside the tile reads from LDS (rdf_device.hpp)
-    // (made visible by the first tile's barriers)
-
+    if (tid == 0) s_tile[2] = s_tile[3] = 0u;   // (made visible by the first tile's barrier)
     unsigned long long st_px = 0, st_lv = 0, st_lf = 0;
     const char *depth_b = reinterpret_cast<const char *>(a.depth);
     const int tw = a.tw, th = a.th, twp = a.twp;
@@ -340,7 +440,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
         const int tx0 = (int)(tx * 64u) * a.r - a.halo;
         const int ty0 = (int)(ty * tile_rows) * a.r - a.halo;
 
-        const ProbeCtx pc = {lds_tile, depth_b + img_boff, tx0, ty0, tw, th, twp, a.W, a.H};
+        const TileCtx pc = {depth_b + img_boff,
+                            (uint32_t)tw * 2u, (uint32_t)th, (uint32_t)twp * 2u, (uint32_t)a.W * 2u, (uint32_t)a.H,
+                            (uint32_t)tx0 * 2u, (uint32_t)ty0};
 
         // ---- empty tile?  (live frames are mostly background.)  Every wave looks at the centre depths of its
         // own rows straight from global memory; a tile without a single pixel to evaluate is not staged.
@@ -361,7 +463,15 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                     if (!ok && a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
                 }
             }
-            if (!__syncthreads_or(mine ? 1 : 0)) continue;   // block-uniform
+            // workgroup-wide OR through two alternating mailbox words (__syncthreads_or would bring the runtime's static
+            // LDS scratch, which moves the depth tile away from LDS address 0): the word of tile `it` is cleared again
+            // by thread 0 during tile it + 1, after that tile's barrier -- every wave has read it by then, and nobody
+            // writes it before the barrier at the top of tile it + 2
+            if (__any(mine) && lane == 0) s_tile[2u + (it & 1u)] = 1u;
+            __syncthreads();
+            const uint32_t any_mine = s_tile[2u + (it & 1u)];
+            if (tid == 0) s_tile[2u + ((it + 1u) & 1u)] = 0u;
+            if (any_mine == 0u) continue;   // block-uniform
         }
 
         // ---- stage depth [ty0, ty0+th) x [tx0, tx0+tw) into LDS; outside the image = 65535 ----
@@ -421,7 +531,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                 const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
                 if (a.filter_class != -1) ok = (int)a.filter[i] == a.filter_class;
                 if (ok) {
-                    const uint32_t d = (uint32_t)probe_value(probe_issue(pc, lx * a.r - tx0, ly * a.r - ty0));
+                    const uint32_t d = (uint32_t)tprobe_value(tprobe_issue(pc, (uint32_t)(lx * a.r - tx0) * 2u, (uint32_t)(ly * a.r - ty0)));
                     ok = d != 0u && d != kNoPixel;
                 }
                 if (!ok && a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
@@ -512,18 +622,21 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
             bool skip = false;
             if (!compact && a.filter_class != -1) skip = (int)a.filter[i] != a.filter_class;
             uint32_t d = 0u;
-            if (!skip) d = (uint32_t)probe_value(probe_issue(pc, xl, yl));
+            if (!skip) d = (uint32_t)tprobe_value(tprobe_issue(pc, (uint32_t)xl * 2u, (uint32_t)yl));
             if (!compact && (skip || d == 0u || d == kNoPixel)) {
                 if (a.fill_untouched && (!TW || tw_tree == 0u)) a.labels[i] = (uint16_t)kNoPixel;
                 continue;
             }
             const float df = (float)d;
-            // refined reciprocal shared by every divide of this pixel (fast path only)
+            // refined reciprocal shared by every divide of this pixel (fast path only), in round-to-nearest
             const float r0 = __builtin_amdgcn_rcpf(df);
             const float rcp = __builtin_fmaf(__builtin_fmaf(-df, r0, 1.0f), r0, r0);
-            const float rcp_s = rcp * (1.0f / kNumScale), df_s = df * kNumScale;   // exact scalings
-            const f2 rcp2 = {rcp_s, rcp_s};
-            const f2 ndf2 = {-df_s, -df_s};
+            float rcp_s = rcp * (1.0f / kNumScale);                           // exact scalings
+            const float df_s = df * kNumScale;
+            // coordinate = bits(fma(n, rcp_s, kMagic)) + (pixel coordinate - kMagicBits), x doubled (NodeRec16, TileCtx)
+            uint32_t kx2 = ((uint32_t)xl - kMagicBits) * 2u;
+            const uint32_t ky = (uint32_t)yl - kMagicBits;
+            pin(kx2);     // (opaque: bits * 2 + kx2 stays one v_lshl_add_u32)
 
             float best = 0.0f;
             int best_c = 0;
@@ -542,6 +655,14 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 #pragma unroll
                     for (int k = 0; k < GROUP; ++k) h[k] = (kb + k) < a.T ? 1u : kIdle;
 
+                    // The level loop runs in round-down mode (NodeRec16).  The sums of the previous group's leaf PDFs
+                    // are pinned in front of the switch; the reference-layout kernel switches back for good at its
+                    // first level below the staged ones, where every node takes the IEEE divide.
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) pin(pdf[c]);
+                    const bool fast_levels = PACKED || K > 0;
+                    if (fast_levels) set_round_down(rcp_s);
+
                     for (int j = 0; j < a.D; ++j) {
                         bool any = false;
 #pragma unroll
@@ -549,10 +670,13 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                         if (!__any(any)) break;
 
                         const bool in_lds = j < K;
+                        float df_e = df;     // (a copy the mode switches tie)
+                        if (!PACKED && fast_levels && j == K) set_round_nearest(df_e);
                         Node n[GROUP];
-                        uint32_t hn[GROUP];   // node to fetch: a finished or idle slot reads the level's first node (discarded)
+                        uint32_t hn[GROUP];   // node to fetch: a finished (negative) or idle slot reads the level's first node (discarded);
+                                              // a walking slot's node is >= 2^j
 #pragma unroll
-                        for (int k = 0; k < GROUP; ++k) hn[k] = (int)h[k] > 0 ? h[k] : (1u << j);   // (the level's first node: valid in every table)
+                        for (int k = 0; k < GROUP; ++k) hn[k] = (uint32_t)max((int)h[k], 1 << j);
                         if (in_lds) {
 #pragma unroll
                             for (int k = 0; k < GROUP; ++k) {
@@ -574,19 +698,22 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                 const f4u uv = *reinterpret_cast<const f4u *>(p);
                                 const f3u tf = *reinterpret_cast<const f3u *>(p + 4);
                                 n[k].ax = a.s * uv.x; n[k].ay = a.s * uv.y; n[k].bx = a.s * uv.z; n[k].by = a.s * uv.w;
-                                n[k].t = thresh_to_int(tf.x);
+                                set_threshold(n[k], thresh_to_int(tf.x));
                                 n[k].flags = child_flags(tf.y, tf.z) | kFlagExact;   // fp32 numerators: IEEE divide
                             }
                         }
 
-                        // ---- probe coordinates x + floor((s*u.x)/d) ... (decision_tree_common.hpp:15-22), kept relative to the tile ----
-                        int ux[GROUP], uy[GROUP], vx[GROUP], vy[GROUP];
+                        // ---- probe coordinates x + floor((s*u.x)/d) ... (decision_tree_common.hpp:15-22), relative to the
+                        // staged tile, x doubled ----
+                        uint32_t ux[GROUP], uy[GROUP], vx[GROUP], vy[GROUP];
                         uint32_t fl = 0u;
 #pragma unroll
                         for (int k = 0; k < GROUP; ++k) fl |= n[k].flags;
                         if (__any((fl & kFlagExact) != 0u)) {
                             // some lane holds a node whose numerators are not integer-representable: fetch the
-                            // fp32 numerators for those lanes and divide IEEE (every lane: same results)
+                            // fp32 numerators for those lanes and divide IEEE, in round-to-nearest (every lane: same results)
+                            const bool switch_mode = PACKED || in_lds;
+                            if (switch_mode) set_round_nearest(df_e);
                             if (PACKED || in_lds) {
 #pragma unroll
                                 for (int k = 0; k < GROUP; ++k) {
@@ -608,49 +735,61 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 #pragma unroll
                             for (int k = 0; k < GROUP; ++k) {
                                 // lanes on an ordinary node still hold kNumScale * (x + e): same floor (NodeRec16)
-                                const float den = (n[k].flags & kFlagExact) ? df : df_s;
-                                ux[k] = add_wrap(xl, floor_i32(n[k].ax / den));
-                                uy[k] = add_wrap(yl, floor_i32(n[k].ay / den));
-                                vx[k] = add_wrap(xl, floor_i32(n[k].bx / den));
-                                vy[k] = add_wrap(yl, floor_i32(n[k].by / den));
+                                const float den = (n[k].flags & kFlagExact) ? df_e : df_s;
+                                // (x is doubled afterwards: a wrapped x + INT_MAX stays far outside every tile and image
+                                // when held to +-2^30 first)
+                                ux[k] = (uint32_t)min(max(add_wrap(xl, floor_i32(n[k].ax / den)), -(1 << 30)), (1 << 30) - 1) * 2u;
+                                uy[k] = (uint32_t)add_wrap(yl, floor_i32(n[k].ay / den));
+                                vx[k] = (uint32_t)min(max(add_wrap(xl, floor_i32(n[k].bx / den)), -(1 << 30)), (1 << 30) - 1) * 2u;
+                                vy[k] = (uint32_t)add_wrap(yl, floor_i32(n[k].by / den));
+                            }
+                            if (switch_mode) {
+#pragma unroll
+                                for (int k = 0; k < GROUP; ++k) { pin(ux[k]); pin(uy[k]); pin(vx[k]); pin(vy[k]); }
+                                set_round_down(ux[0]);
                             }
                         } else {
-                            // q0 = a*rcp; rem = a - d*q0 (exact, fma); q = q0 + rem*rcp.  Packed f32 math,
-                            // two quotients per instruction.
+                            // divide, floor and add in two instructions per coordinate: t = fma(n, r/512, 1.5 * 2^23) rounded down
+                            // holds floor(x/d) in its mantissa (NodeRec16; tools/verify_magic.hip)
 #pragma unroll
                             for (int k = 0; k < GROUP; ++k) {
                                 const f2 nu = {n[k].ax, n[k].ay};
                                 const f2 nv = {n[k].bx, n[k].by};
-                                const f2 qu0 = nu * rcp2;
-                                const f2 qv0 = nv * rcp2;
-                                const f2 ru = __builtin_elementwise_fma(ndf2, qu0, nu);
-                                const f2 rv = __builtin_elementwise_fma(ndf2, qv0, nv);
-                                const f2 qu = __builtin_elementwise_fma(ru, rcp2, qu0);
-                                const f2 qv = __builtin_elementwise_fma(rv, rcp2, qv0);
-                                ux[k] = add_wrap(xl, floor_i32_not_nan(qu.x));
-                                uy[k] = add_wrap(yl, floor_i32_not_nan(qu.y));
-                                vx[k] = add_wrap(xl, floor_i32_not_nan(qv.x));
-                                vy[k] = add_wrap(yl, floor_i32_not_nan(qv.y));
+                                const f2 r2 = {rcp_s, rcp_s};
+                                const f2 m2 = {kMagic, kMagic};
+                                const f2 tu = __builtin_elementwise_fma(nu, r2, m2);
+                                const f2 tv = __builtin_elementwise_fma(nv, r2, m2);
+                                ux[k] = (__float_as_uint(tu.x) << 1) + kx2;
+                                uy[k] = __float_as_uint(tu.y) + ky;
+                                vx[k] = (__float_as_uint(tv.x) << 1) + kx2;
+                                vy[k] = __float_as_uint(tv.y) + ky;
                             }
                         }
 
-                        Probe qu[GROUP], qv[GROUP];
+                        TileProbe qu[GROUP], qv[GROUP];
 #pragma unroll
                         for (int k = 0; k < GROUP; ++k) {
-                            qu[k] = probe_issue(pc, ux[k], uy[k]);
-                            qv[k] = probe_issue(pc, vx[k], vy[k]);
+                            qu[k] = tprobe_issue(pc, ux[k], uy[k]);
+                            qv[k] = tprobe_issue(pc, vx[k], vy[k]);
                         }
 
-                        // ---- decide (tree_eval.cu:107-121), branch-free ----
+                        // ---- decide (tree_eval.cu:107-121) ----
 #pragma unroll
                         for (int k = 0; k < GROUP; ++k) {
                             const bool walking = (int)h[k] > 0;
                             if (STATS && c0 == 0) st_lv += walking ? 1u : 0u;
-                            const uint32_t side = (probe_value(qu[k]) - probe_value(qv[k])) < n[k].t ? 0u : 1u;
-                            const uint32_t stop = (n[k].flags >> side) & 1u;           // kFlagLeftLeaf = bit 0, kFlagRightLeaf = bit 1
-                            const uint32_t next = ((h[k] << 1) | side) | (stop << 31);  // low bits: (node-1)*2 + side + 2
+                            const int g = tprobe_value(qu[k]) - tprobe_value(qv[k]) - (int)n[k].lo16;
+                            const uint32_t next = walk_step(h[k], g, n[k].w2, n[k].flags);   // low bits: (node-1)*2 + side + 2
                             h[k] = walking ? next : h[k];
                         }
+                    }
+                    // back to round-to-nearest for the sums of leaf PDFs (tied to the walk's results)
+                    if (fast_levels) {
+#pragma unroll
+                        for (int k = 0; k < GROUP; ++k) pin(h[k]);
+                        set_round_nearest(h[0]);
+#pragma unroll
+                        for (int k = 0; k < GROUP; ++k) pin(h[k]);
                     }
 
                     if (TW) { tw_h = h[0]; break; }       // the trees meet in LDS, below the pixel loop
@@ -1021,6 +1160,14 @@ std::map<std::tuple<int, const void *, int>, int> g_occ_cache;   // (device, ker
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
 int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st);
 
+// The forest kernel addresses its depth tile as LDS address 0 + byte offset (TileCtx): true as long as the kernel has no
+// static LDS in front of the dynamic allocation.  Checked once per kernel; a build that breaks it fails loudly.
+bool tile_at_lds_zero(const void *kernel)
+{
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, kernel) == hipSuccess && fa.sharedSizeBytes == 0;
+}
+
 // Filtered launches (a layer that only looks at one class of an earlier layer) list the pixels to evaluate first and
 // deal them to the waves 64 at a time (COMPACT); these exist for 256- and 512-thread workgroups.
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
@@ -1049,6 +1196,7 @@ int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
             hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) return (int)e;
         }
+        if (!tile_at_lds_zero(kp)) return RDF_ERR_NO_DEVICE;
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, BLOCK, (size_t)lds_bytes) != hipSuccess || n < 1)
             n = 1;
@@ -1089,6 +1237,7 @@ int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st
             hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) return (int)e;
         }
+        if (!tile_at_lds_zero(kp)) return RDF_ERR_NO_DEVICE;
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kBlock, (size_t)lds_bytes) != hipSuccess || n < 1) n = 1;
         per_cu = n;
@@ -1259,7 +1408,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
 
-    // ---- LDS plan: [node table: T*2^K*16 B][16 B whose last cell is the 65535 sentinel][depth tile: th*twp*2 B][queue mailbox 16 B][pixel list] ----
+    // ---- LDS plan: [depth tile: th*twp*2 B, at address 0][node table: T*2^K*16 B][queue mailbox 32 B][pixel list] ----
     const long long budget = lds_budget(tw ? 256 : block);
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
     const bool compact_launch = (block == 256 || block == 512) && !stats && filter_class != -1 && g_compaction != 0;
@@ -1319,9 +1468,9 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
            (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 32 + list_bytes <= budget) ++K;
     a.lds_levels = K;
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
-    a.lds_tile_off = (uint32_t)(node_bytes + 16);
-    a.lds_mail_off = (uint32_t)(node_bytes + 16 + tile_bytes);
-    a.lds_list_off = (uint32_t)(node_bytes + 32 + tile_bytes);
+    a.lds_nodes_off = (uint32_t)tile_bytes;
+    a.lds_mail_off = (uint32_t)(tile_bytes + node_bytes);
+    a.lds_list_off = (uint32_t)(tile_bytes + node_bytes + 32);
     a.lds_xchg_off = a.lds_list_off;
     const int lds_bytes = (int)(node_bytes + tile_bytes + 32 + list_bytes);
     if (plan_only) {
