@@ -61,6 +61,8 @@ SIGNATURES = {
     "rdf_fill_u16": (_c_int, [_c_void_p, _c_size_t, ctypes.c_uint16, _c_void_p]),
     "rdf_stream_create_with_reserved_cus": (_c_int, [_c_void_p, _c_int]),
     "rdf_stream_destroy": (_c_int, [_c_void_p]),
+    "rdf_stream_capture_id": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
+    "rdf_graph_slots_release": (_c_int, [ctypes.c_uint64]),
     "rdf_debug_sched_slots": (_c_int, [_c_void_p, _c_void_p]),
     "rdf_device_malloc": (_c_int, [_c_void_p, _c_size_t]),
     "rdf_device_free": (_c_int, [_c_void_p]),

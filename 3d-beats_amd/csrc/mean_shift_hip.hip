@@ -309,7 +309,8 @@ static int mean_shift_launch(const uint16_t *labels, int dim_x, int dim_y, int n
         return RDF_ERR_BAD_ARG;
     if (num_classes == 0) return RDF_OK;
     if ((long long)dim_x * dim_y >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
-    if (!means_out || (num_rounds > 0 && (!labels || !variances))) return RDF_ERR_NULL_PTR;
+    // the kernel lists every class's pixels and reads variances[0 .. num_classes) whatever the number of rounds
+    if (!means_out || (((long long)dim_x * dim_y > 0) && !labels) || !variances) return RDF_ERR_NULL_PTR;
     const int lds_bytes = (int)(kMsListCap * sizeof(uint32_t));
     const void *kp = heights ? reinterpret_cast<const void *>(k_mean_shift_fused<true>)
                              : reinterpret_cast<const void *>(k_mean_shift_fused<false>);

@@ -34,9 +34,11 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <tuple>
 #include <mutex>
@@ -320,8 +322,8 @@ __device__ __forceinline__ int tprobe_value(const TileProbe &p)
     return (int)(p.in_tile ? l : g);
 }
 
-// FULLROWS: every wave owns kMaxRowsPerWave label rows of the tile (throughput shape); otherwise
-// a.rows_per_wave rows (latency shape for small launches such as one live frame).
+// Every wave owns a.rows_per_wave label rows of the tile (up to kMaxRowsPerWave in the throughput shape, one for small
+// launches such as one live frame).
 // NL > 1 ("layers in one launch", small launches of a layered stack): workgroup b evaluates forest b % NL of the kernel's
 // NL argument sets on the same frame -- NL independent forest evaluations that share ONE launch, hence one ramp and one
 // drain (a small launch costs one wave-row's dependent chain however little it evaluates), with a tile queue per role.
@@ -330,7 +332,7 @@ struct EvalArgsN {
     EvalArgs l[NL];
 };
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT, int NL = 1, bool TW = false>
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT, int NL = 1, bool TW = false>
 // second launch bound = waves per SIMD the register allocation must allow: three 512-thread workgroups per CU are six
 // waves per SIMD (80 VGPRs; the 4-wide walk needs 86 without the bound and spills two dwords with it)
 __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgsN<NL> ka)
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
     const int K = a.lds_levels;
     const uint32_t nodes_lds = (1u << K) - 1u;
     constexpr uint32_t kWaves = BLOCK / 64;
-    const int rows_per_wave = FULLROWS ? kMaxRowsPerWave : a.rows_per_wave;
+    const int rows_per_wave = a.rows_per_wave;
     const uint32_t wave = (uint32_t)tid >> 6;
     // TW ("tree waves", small launches): the T trees of a forest are walked by T different waves -- wave w takes tree
     // w % T for pixel row w / T of the tile -- and meet in LDS.  A wave alone on its SIMD issues an instruction every
@@ -1036,8 +1038,11 @@ __global__ void k_debug_div(const float *num, const float *den, float *out, size
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-int g_lds_budget = 0;
-int g_block_threads = 0;
+// Tuning / test knobs: process-wide, each read once per call (atomic: a library two threads use must not tear them; a
+// call that overlaps a change sees the old or the new value)
+typedef std::atomic<int> Knob;
+Knob g_lds_budget{0};
+Knob g_block_threads{0};
 
 int env_int(const char *name, int dflt)
 {
@@ -1048,7 +1053,8 @@ int env_int(const char *name, int dflt)
 int lds_budget(int block)
 {
     // per workgroup: five 256-thread or three 512-thread workgroups share a CU's 160 KB
-    int b = g_lds_budget > 0 ? g_lds_budget : env_int("RDF_LDS_BUDGET", block == 512 ? kDefaultLdsBudget512 : kDefaultLdsBudget);
+    const int knob = g_lds_budget;
+    int b = knob > 0 ? knob : env_int("RDF_LDS_BUDGET", block == 512 ? kDefaultLdsBudget512 : kDefaultLdsBudget);
     if (b > 160 * 1024) b = 160 * 1024;
     if (b < 0) b = 0;
     return b;
@@ -1077,10 +1083,10 @@ int device_info(DeviceInfo *out)
 std::mutex g_sched_mu;
 std::map<std::tuple<int, void *, int>, int> g_sched_slot;   // (device, stream, role of a multi-forest launch) -> slot
 std::map<int, unsigned int *> g_sched_base;     // device -> address of g_sched on that device
-int g_compaction = -1;                          // -1: filtered launches compact their pixels; 0: never
-int g_group = 0;                                // 0: trees per lane chosen by forest size; 1..4: forced (rdf_set_group)
-int g_layers_one_launch = -1;                   // -1/1: small packed layered runs evaluate their layers in one launch; 0: never
-int g_sched_mode = -1;                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic, 2 one tile per workgroup
+Knob g_compaction{-1};                          // -1: filtered launches compact their pixels; 0: never
+Knob g_group{0};                                // 0: trees per lane chosen by forest size; 1..4: forced (rdf_set_group)
+Knob g_layers_one_launch{-1};                   // -1/1: small packed layered runs evaluate their layers in one launch; 0: never
+Knob g_sched_mode{-1};                          // -1: env RDF_SCHED (default dynamic), 0 static, 1 dynamic, 2 one tile per workgroup
 
 int sched_mode()
 {
@@ -1094,7 +1100,10 @@ int sched_mode()
 
 std::map<int, std::vector<int>> g_sched_free;   // device -> stream slots given back by rdf_stream_destroy
 std::map<int, int> g_sched_next;                // device -> stream slots handed out so far
-std::map<int, int> g_graph_next;                // device -> graph slots handed out so far
+std::map<int, int> g_graph_next;                // device -> graph slots handed out so far (never handed out twice at once)
+std::map<int, std::vector<int>> g_graph_free;   // device -> graph slots given back by rdf_graph_slots_release
+std::map<std::pair<int, unsigned long long>, std::vector<int>> g_graph_by_capture;   // (device, capture id) -> its slots
+bool g_graph_exhausted_logged = false;
 
 unsigned int *sched_slot(void *stream, int role = 0)
 {
@@ -1109,11 +1118,29 @@ unsigned int *sched_slot(void *stream, int role = 0)
         bit = g_sched_base.emplace(dev, reinterpret_cast<unsigned int *>(p)).first;
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (stream && hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) == hipSuccess &&
+    unsigned long long cap_id = 0;
+    if (stream && hipStreamGetCaptureInfo(reinterpret_cast<hipStream_t>(stream), &cap, &cap_id) == hipSuccess &&
         cap == hipStreamCaptureStatusActive) {
-        int &n = g_graph_next[dev];
-        if (n >= kGraphSlots) return nullptr;   // static tiles: slower on uneven batches, never wrong
-        return bit->second + kSchedWords * (kSchedSlots + n++);
+        // a slot of its own for every launch recorded into a graph, remembered under the capture's id so that the owner of
+        // the graph can give the slots back (rdf_graph_slots_release) when the executable graph is gone
+        int slot = -1;
+        auto &fl = g_graph_free[dev];
+        if (!fl.empty()) {
+            slot = fl.back();
+            fl.pop_back();
+        } else if (g_graph_next[dev] < kGraphSlots) {
+            slot = g_graph_next[dev]++;
+        }
+        if (slot < 0) {   // static tiles: slower on uneven batches, never wrong -- but say so once
+            if (!g_graph_exhausted_logged) {
+                g_graph_exhausted_logged = true;
+                fprintf(stderr, "librdf_hip: all %d tile-queue slots for graph-captured launches are taken; further captured "
+                                "launches use static tiles (release graphs' slots with rdf_graph_slots_release)\n", kGraphSlots);
+            }
+            return nullptr;
+        }
+        g_graph_by_capture[std::make_pair(dev, cap_id)].push_back(slot);
+        return bit->second + kSchedWords * (kSchedSlots + slot);
     }
     const auto key = std::make_tuple(dev, stream, role);
     auto it = g_sched_slot.find(key);
@@ -1157,9 +1184,6 @@ struct LaunchGeom {
 };
 std::map<std::tuple<int, const void *, int>, int> g_occ_cache;   // (device, kernel, LDS bytes) -> workgroups per CU
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
-int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st);
-
 // The forest kernel addresses its depth tile as LDS address 0 + byte offset (TileCtx): true as long as the kernel has no
 // static LDS in front of the dynamic allocation.  Checked once per kernel; a build that breaks it fails loudly.
 bool tile_at_lds_zero(const void *kernel)
@@ -1168,20 +1192,10 @@ bool tile_at_lds_zero(const void *kernel)
     return hipFuncGetAttributes(&fa, kernel) == hipSuccess && fa.sharedSizeBytes == 0;
 }
 
-// Filtered launches (a layer that only looks at one class of an earlier layer) list the pixels to evaluate first and
-// deal them to the waves 64 at a time (COMPACT); these exist for 256- and 512-thread workgroups.
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP>
-int launch_group(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT>
+int launch_one(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    if ((BLOCK == 256 || BLOCK == 512) && !STATS && a.filter_class != -1 && g_compaction != 0)   // == compact_launch in eval_common, which sized the LDS for it
-        return launch_compact<(BLOCK == 512 ? 512 : 256), PACKED, CMAX, false, FULLROWS, GROUP, true>(a, lds_bytes, cus, st);
-    return launch_compact<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP, false>(a, lds_bytes, cus, st);
-}
-
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS, int GROUP, bool COMPACT>
-int launch_compact(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
-{
-    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, FULLROWS, GROUP, COMPACT>;
+    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, GROUP, COMPACT>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
@@ -1222,7 +1236,7 @@ template <int CMAX, int NL, bool TW = false>
 int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st)
 {
     constexpr int kBlock = TW ? 512 : 256;      // tree waves: 8 waves = 8 / T pixel rows x T trees
-    auto kern = k_eval_forest<kBlock, true, CMAX, false, false, TW ? 1 : kGroup, false, NL, TW>;
+    auto kern = k_eval_forest<kBlock, true, CMAX, false, TW ? 1 : kGroup, false, NL, TW>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
@@ -1254,46 +1268,52 @@ int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st
     return (int)hipGetLastError();
 }
 
-// A lane walks GROUP trees interleaved.  Forests of one, two, three or six trees (and `rdf_eval_tree`) get kernels without the
-// idle slots of the 4-wide one (measured: T = 1 costs 54 % of T = 4 with idle slots); these exist for the default
-// workgroup size only.
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, bool FULLROWS>
-int launch_rows(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+// Which instantiations exist (49 kernels; every one costs a second of compile time and ~20 KB of code object, so the list is
+// what launches really take -- rows per wave, halo, LDS levels, scheduler are run-time arguments):
+//   packed table, no pixel list:         256 / 512 threads x 4 / 8 / 16 classes in registers x 1 / 2 / 3 / 4 trees in a lane
+//   packed table, filtered (pixel list): 256 / 512 threads x 4 / 8 / 16 classes x 4 trees in a lane
+//   reference-layout forest:             256 / 512 threads x 4 / 16 classes x 1 or 4 trees in a lane (a filtered launch
+//                                        takes the early-outs per lane instead of listing pixels)
+//   visit counters (rdf_eval_forest_stats): reference layout, 256 threads, classes four at a time
+//   layers of a stack / tree waves in one launch: launch_multi, 4 / 8 classes
+// A lane walks GROUP trees interleaved: forests of one, two, three or six trees (and `rdf_eval_tree`) get kernels without the
+// idle slots of the 4-wide one (measured: T = 1 costs 54 % of T = 4 with idle slots).  rdf_set_group overrides the choice by
+// forest size (any width is correct for any forest: slots beyond the last tree idle).
+int group_for(const EvalArgs &a, bool packed)
 {
-    if (BLOCK == 256 && !STATS) {
-        // trees a lane walks interleaved; rdf_set_group overrides the choice by forest size (any width is correct for any
-        // forest: slots beyond the last tree idle)
-        const int g = g_group > 0 ? g_group : (a.T == 1 ? 1 : a.T == 2 ? 2 : (a.T == 3 || a.T == 6) ? 3 : 4);
-        if (g == 1) return launch_group<256, PACKED, CMAX, false, FULLROWS, 1>(a, lds_bytes, cus, st);
-        if (g == 2) return launch_group<256, PACKED, CMAX, false, FULLROWS, 2>(a, lds_bytes, cus, st);
-        if (g == 3) return launch_group<256, PACKED, CMAX, false, FULLROWS, 3>(a, lds_bytes, cus, st);
+    const int knob = g_group;
+    const int g = knob > 0 ? knob : (a.T == 1 ? 1 : a.T == 2 ? 2 : (a.T == 3 || a.T == 6) ? 3 : 4);
+    return packed ? g : (g == 1 ? 1 : 4);
+}
+
+template <int BLOCK, bool PACKED, int CMAX>
+int launch_group(bool compact, const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+{
+    const int g = group_for(a, PACKED);
+    if constexpr (PACKED) {
+        if (compact) return launch_one<BLOCK, true, CMAX, false, 4, true>(a, lds_bytes, cus, st);
+        switch (g) {
+        case 1: return launch_one<BLOCK, true, CMAX, false, 1, false>(a, lds_bytes, cus, st);
+        case 2: return launch_one<BLOCK, true, CMAX, false, 2, false>(a, lds_bytes, cus, st);
+        case 3: return launch_one<BLOCK, true, CMAX, false, 3, false>(a, lds_bytes, cus, st);
+        default: return launch_one<BLOCK, true, CMAX, false, 4, false>(a, lds_bytes, cus, st);
+        }
+    } else {
+        return g == 1 ? launch_one<BLOCK, false, CMAX, false, 1, false>(a, lds_bytes, cus, st)
+                      : launch_one<BLOCK, false, CMAX, false, 4, false>(a, lds_bytes, cus, st);
     }
-    return launch_group<BLOCK, PACKED, CMAX, STATS, FULLROWS, kGroup>(a, lds_bytes, cus, st);
 }
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS>
-int launch_variant(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+template <int BLOCK>
+int launch_block(bool packed, bool compact, const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    return a.rows_per_wave == kMaxRowsPerWave ? launch_rows<BLOCK, PACKED, CMAX, STATS, true>(a, lds_bytes, cus, st)
-                                              : launch_rows<BLOCK, PACKED, CMAX, STATS, false>(a, lds_bytes, cus, st);
-}
-
-template <int BLOCK, bool PACKED, bool STATS>
-int launch_cmax(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
-{
-    if (a.C <= 4) return launch_variant<BLOCK, PACKED, 4, STATS>(a, lds_bytes, cus, st);
-    if (a.C <= 8) return launch_variant<BLOCK, PACKED, 8, STATS>(a, lds_bytes, cus, st);
-    return launch_variant<BLOCK, PACKED, 16, STATS>(a, lds_bytes, cus, st);
-}
-
-template <bool PACKED, bool STATS>
-int launch_block(int block, const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
-{
-    switch (block) {
-    case 256: return launch_cmax<256, PACKED, STATS>(a, lds_bytes, cus, st);
-    case 512: return launch_cmax<512, PACKED, STATS>(a, lds_bytes, cus, st);
-    default: return launch_cmax<1024, PACKED, STATS>(a, lds_bytes, cus, st);
+    if (packed) {
+        if (a.C <= 4) return launch_group<BLOCK, true, 4>(compact, a, lds_bytes, cus, st);
+        if (a.C <= 8) return launch_group<BLOCK, true, 8>(compact, a, lds_bytes, cus, st);
+        return launch_group<BLOCK, true, 16>(compact, a, lds_bytes, cus, st);
     }
+    if (a.C <= 4) return launch_group<BLOCK, false, 4>(false, a, lds_bytes, cus, st);
+    return launch_group<BLOCK, false, 16>(false, a, lds_bytes, cus, st);
 }
 
 int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void *forest, int n_trees,
@@ -1310,12 +1330,12 @@ int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void 
     return 0;
 }
 
-int g_halo = -1;
-int g_lds_levels = -1;
-int g_tree_waves = -1;
-int g_stage_vec = -1;
-int g_rows_per_wave = 0;
-int g_force_exact = 0;
+Knob g_halo{-1};
+Knob g_lds_levels{-1};
+Knob g_tree_waves{-1};
+Knob g_stage_vec{-1};
+Knob g_rows_per_wave{0};
+Knob g_force_exact{0};
 
 // What eval_common works out before it launches: the kernel arguments (without a queue slot), the dynamic LDS and the
 // geometry.  layered_run asks for the plan only (plan_only) to put several layers into one launch.
@@ -1372,12 +1392,16 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // Workgroup size.  Big unfiltered launches: 512 threads, three workgroups per CU = 24 waves with a 48-pixel halo
     // (54 KB of LDS each) instead of five 256-thread workgroups = 20 waves with 32 pixels: 4.77 vs 5.14 ms on the bench
     // batch, 11.45 vs 12.60 ms on config 5's shard (profiles/r02_sweep_512.txt).  Small launches keep 256 threads.
-    int block = g_block_threads > 0 ? g_block_threads : env_int("RDF_BLOCK", 0);
+    const int block_knob = g_block_threads;
+    int block = block_knob > 0 ? block_knob : env_int("RDF_BLOCK", 0);
     // (filtered launches at labels_reduce 1 gain nothing from 512 threads: 1.36 ms either way, 1.63 with this default's
     // halo; at labels_reduce 2 they do: 0.46 vs 0.55 ms)
-    const bool filtered_r1 = filter_class != -1 && g_compaction != 0 && r == 1;
-    if (block != 256 && block != 512 && block != 1024) block = (big && !stats && !filtered_r1) ? 512 : 256;
-    int rpw = g_rows_per_wave > 0 ? g_rows_per_wave : env_int("RDF_ROWS_PER_WAVE", 0);
+    const bool compaction = g_compaction != 0;
+    const bool filtered_r1 = packed && filter_class != -1 && compaction && r == 1;
+    if (block != 256 && block != 512) block = (big && !filtered_r1) ? 512 : 256;   // (other requests: the default)
+    if (stats) block = 256;
+    const int rpw_knob = g_rows_per_wave;
+    int rpw = rpw_knob > 0 ? rpw_knob : env_int("RDF_ROWS_PER_WAVE", 0);
     if (rpw < 1 || rpw > kMaxRowsPerWave) {
         rpw = kMaxRowsPerWave;
         if (big && block == 512) {
@@ -1397,8 +1421,9 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // a tile now needs four times the wave slots, and a dense 848x480 frame at full resolution got slower (82 -> 95 us with
     // the 1 024-thread shape; live: 48 -> 42).  The layers of a stack evaluated in one launch (rdf_layered_run) take the
     // same shape when every layer can.
-    const int want_tw = g_tree_waves >= 0 ? g_tree_waves : env_int("RDF_TREE_WAVES", 1);
-    const bool tw = allow_tw && want_tw != 0 && !big && !stats && packed && filter_class == -1 && block == 256 && n_trees >= 2 && n_trees <= 4 &&
+    const int tw_knob = g_tree_waves;
+    const int want_tw = tw_knob >= 0 ? tw_knob : env_int("RDF_TREE_WAVES", 1);
+    const bool tw = allow_tw && want_tw != 0 && !big && !stats && packed && filter_class == -1 && block == 256 && n_trees >= 2 && n_trees <= 4 && n_classes <= 8 &&
                     max_depth >= 1 && sched_mode() != 2 && (long long)n_img * a.Wl * a.Hl <= 131072;
     if (tw) { rpw = 1; block = 512; }
     a.rows_per_wave = rpw;
@@ -1411,7 +1436,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // ---- LDS plan: [depth tile: th*twp*2 B, at address 0][node table: T*2^K*16 B][queue mailbox 32 B][pixel list] ----
     const long long budget = lds_budget(tw ? 256 : block);
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
-    const bool compact_launch = (block == 256 || block == 512) && !stats && filter_class != -1 && g_compaction != 0;
+    const bool compact_launch = packed && !stats && filter_class != -1 && compaction;
     // Halo and the levels that must stay in LDS, by measurement (profiles/r02_sweep_*.txt).  256-thread workgroups (32.7 KB):
     // four trees 7 levels + 32 px (5.17 ms; 8 + 24: 5.26, 6 + 40: 5.61), eight trees 5 levels + 40 px (config 5's shape:
     // 12.68 ms; 6 + 32: 12.90).  512-thread workgroups (54.6 KB): 56 px with 7 levels (4.74 ms; 8 + 48: 4.76) or, for eight
@@ -1419,7 +1444,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     const bool many_trees = n_trees >= 8;
     // (labels_reduce 2, 64 frames, 512 threads: 6 levels + 32 px 0.81 ms, 7 + 40 0.89 ms -- a tile spans r times the pixels)
     const int halo_default = block == 512 ? (r > 1 ? 32 : 56) : (many_trees ? kDefaultHalo + 8 : kDefaultHalo);
-    int halo = g_halo >= 0 ? g_halo : env_int("RDF_HALO", halo_default);
+    const int halo_knob = g_halo;
+    int halo = halo_knob >= 0 ? halo_knob : env_int("RDF_HALO", halo_default);
     long long tile_bytes = 0;
     // The staged tile may take half the budget.  With labels_reduce > 1 a tile spans r times the pixels per label, so
     // the halo shrinks (by twos) until the tile fits -- a narrow tile still beats none: 64 frames at r = 2 take 1.08 ms
@@ -1433,7 +1459,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
                                  compact_launch ? (((long long)block * rpw * 2 + (long long)tile_rows * 4) + 15) & ~15ll : 0;
     // levels of the forest the caller pinned into LDS (rdf_set_lds_levels): the tile then gets all that is left of the
     // budget instead of half of it
-    int k_forced = g_lds_levels >= 0 ? g_lds_levels : env_int("RDF_LDS_LEVELS", -1);
+    const int levels_knob = g_lds_levels;
+    int k_forced = levels_knob >= 0 ? levels_knob : env_int("RDF_LDS_LEVELS", -1);
     if (k_forced > max_depth) k_forced = max_depth;
     while (k_forced > 0 && (long long)n_trees * (1ll << k_forced) * 16 + 32 + list_bytes > budget) --k_forced;
     // otherwise the tile may take what kMinLdsLevels levels of the forest leave: level for level, a level moved from LDS
@@ -1443,7 +1470,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     const int k_floor = k_forced >= 0 ? k_forced : (max_depth < k_min ? max_depth : k_min);
     const long long tile_budget = budget - 32 - list_bytes - (k_floor > 0 ? (long long)n_trees * (1ll << k_floor) * 16 : 0);
     // 16-byte staging needs every row start 16-byte aligned in the image and in LDS
-    const int want_vec = g_stage_vec >= 0 ? g_stage_vec : env_int("RDF_STAGE_VEC", 1);
+    const int vec_knob = g_stage_vec;
+    const int want_vec = vec_knob >= 0 ? vec_knob : env_int("RDF_STAGE_VEC", 1);
     const bool vec_ok = want_vec && dim_x % 8 == 0 && ((64 * r) % 8 == 0) && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0;
     for (int h = halo; h >= h_min && h >= 0; h -= 2) {
         const bool vec = vec_ok && h % 8 == 0;
@@ -1489,16 +1517,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (tw) {
         EvalArgsN<1> ka;
         ka.l[0] = a;
-        if (a.C <= 4) return launch_multi<4, 1, true>(ka, lds_bytes, cus, st);
-        if (a.C <= 8) return launch_multi<8, 1, true>(ka, lds_bytes, cus, st);
-        return launch_multi<16, 1, true>(ka, lds_bytes, cus, st);
+        return a.C <= 4 ? launch_multi<4, 1, true>(ka, lds_bytes, cus, st) : launch_multi<8, 1, true>(ka, lds_bytes, cus, st);
     }
-    if (stats) {
-        return packed ? launch_block<true, true>(block, a, lds_bytes, cus, st)
-                      : launch_block<false, true>(block, a, lds_bytes, cus, st);
-    }
-    return packed ? launch_block<true, false>(block, a, lds_bytes, cus, st)
-                  : launch_block<false, false>(block, a, lds_bytes, cus, st);
+    if (stats)   // (reference layout, 256 threads: eval_common chose both)
+        return launch_one<256, false, 4, true, 4, false>(a, lds_bytes, cus, st);
+    return block == 512 ? launch_block<512>(packed != nullptr, compact_launch, a, lds_bytes, cus, st)
+                        : launch_block<256>(packed != nullptr, compact_launch, a, lds_bytes, cus, st);
 }
 
 } // namespace
@@ -1554,7 +1578,7 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
                        reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total),
                        reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32))),
                        n_classes, classes_padded(n_classes), total,
-                       max_depth, 7 + 2 * n_classes, scale_factor, g_force_exact);
+                       max_depth, 7 + 2 * n_classes, scale_factor, (int)g_force_exact);
     return (int)hipGetLastError();
 }
 
@@ -1612,7 +1636,8 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
     // n_layers.  Two launches on two streams do not get there: a cross-queue event join costs more than it saves
     // (DESIGN.md section 4).  Big launches keep the filtered evaluation, which does less work.
     SpecFilters spec = {};
-    const int want_multi = g_layers_one_launch >= 0 ? g_layers_one_launch : env_int("RDF_LAYERS_ONE_LAUNCH", 1);
+    const int multi_knob = g_layers_one_launch;
+    const int want_multi = multi_knob >= 0 ? multi_knob : env_int("RDF_LAYERS_ONE_LAUNCH", 1);
     if (want_multi && (n_layers == 2 || n_layers == 3) && packed) {
         Plan plans[3];
         bool ok = true;
@@ -1624,7 +1649,7 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
             ok = true; cmax = 4; lds = 0;
             int n_tw = 0;
             for (int i = 0; i < n_layers && ok; ++i) {
-                ok = packed[i] != nullptr && max_depth[i] <= 27 && n_trees[i] > 0 && max_depth[i] > 0;
+                ok = packed[i] != nullptr && max_depth[i] <= 27 && n_trees[i] > 0 && max_depth[i] > 0 && n_classes[i] <= 8;
                 if (!ok) break;
                 const int rc = eval_common(depth, 1, dim_x, dim_y, packed[i], forests[i], n_trees[i], max_depth[i], n_classes[i],
                                            nullptr, -1, layer_labels[i], labels_reduce, 1.0f, 0, nullptr, stream,
@@ -1634,7 +1659,7 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
                 ok = !pl.empty && !pl.big && (pl.block == 256 || pl.tw) && pl.a.rows_per_wave < kMaxRowsPerWave &&
                      pl.a.rows_per_wave == plans[0].a.rows_per_wave && (pl.tw || pl.a.n_tiles == plans[0].a.n_tiles);
                 n_tw += pl.tw ? 1 : 0;
-                cmax = n_classes[i] > 8 ? 16 : (n_classes[i] > 4 && cmax < 8 ? 8 : cmax);
+                cmax = n_classes[i] > 4 ? 8 : cmax;
                 lds = pl.lds_bytes > lds ? pl.lds_bytes : lds;
             }
             tw_all = ok && n_tw == n_layers;
@@ -1648,7 +1673,8 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
             const int cus = usable_cus(st, di.cus);
             for (int i = 0; i < n_layers; ++i) {
                 plans[i].a.sched = sched_slot(stream, i);
-                spec.fl[i] = filter_layer[i];
+                // (a filter class of -1 means "no filter", as tree_eval.cu:81 and the filtered launches have it)
+                spec.fl[i] = filter_class[i] != -1 ? filter_layer[i] : -1;
                 spec.fc[i] = filter_layer[i] >= 0 ? filter_class[i] : -1;
             }
             // (all roles or none on the dynamic queue: a role without a slot would stride over tiles the others pull)
@@ -1659,20 +1685,16 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
                 EvalArgsN<2> ka;
                 ka.l[0] = plans[0].a; ka.l[1] = plans[1].a;
                 if (tw_all)
-                    rc = cmax == 4 ? launch_multi<4, 2, true>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 2, true>(ka, lds, cus, st)
-                                                                                            : launch_multi<16, 2, true>(ka, lds, cus, st);
+                    rc = cmax == 4 ? launch_multi<4, 2, true>(ka, lds, cus, st) : launch_multi<8, 2, true>(ka, lds, cus, st);
                 else
-                    rc = cmax == 4 ? launch_multi<4, 2>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 2>(ka, lds, cus, st)
-                                                                                      : launch_multi<16, 2>(ka, lds, cus, st);
+                    rc = cmax == 4 ? launch_multi<4, 2>(ka, lds, cus, st) : launch_multi<8, 2>(ka, lds, cus, st);
             } else {
                 EvalArgsN<3> ka;
                 ka.l[0] = plans[0].a; ka.l[1] = plans[1].a; ka.l[2] = plans[2].a;
                 if (tw_all)
-                    rc = cmax == 4 ? launch_multi<4, 3, true>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 3, true>(ka, lds, cus, st)
-                                                                                            : launch_multi<16, 3, true>(ka, lds, cus, st);
+                    rc = cmax == 4 ? launch_multi<4, 3, true>(ka, lds, cus, st) : launch_multi<8, 3, true>(ka, lds, cus, st);
                 else
-                    rc = cmax == 4 ? launch_multi<4, 3>(ka, lds, cus, st) : cmax == 8 ? launch_multi<8, 3>(ka, lds, cus, st)
-                                                                                      : launch_multi<16, 3>(ka, lds, cus, st);
+                    rc = cmax == 4 ? launch_multi<4, 3>(ka, lds, cus, st) : launch_multi<8, 3>(ka, lds, cus, st);
             }
             if (rc != RDF_OK) return rc;
             spec.n = n_layers;
@@ -1811,7 +1833,33 @@ int rdf_stream_destroy(void *stream)
     return (int)(d != hipSuccess ? d : e);
 }
 
-// test hook: how many stream slots / graph slots the current device has handed out and how many were given back
+int rdf_stream_capture_id(void *stream, unsigned long long *capture_id)
+{
+    if (!capture_id) return RDF_ERR_NULL_PTR;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    const hipError_t e = hipStreamGetCaptureInfo(reinterpret_cast<hipStream_t>(stream), &cap, &id);
+    if (e != hipSuccess) return (int)e;
+    if (cap != hipStreamCaptureStatusActive) return RDF_ERR_BAD_ARG;
+    *capture_id = id;
+    return RDF_OK;
+}
+
+int rdf_graph_slots_release(unsigned long long capture_id)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    auto it = g_graph_by_capture.find(std::make_pair(dev, capture_id));
+    if (it == g_graph_by_capture.end()) return 0;
+    const int n = (int)it->second.size();
+    auto &fl = g_graph_free[dev];
+    fl.insert(fl.end(), it->second.begin(), it->second.end());
+    g_graph_by_capture.erase(it);
+    return n;
+}
+
+// test hook: how many stream slots / graph slots the current device holds at the moment
 int rdf_debug_sched_slots(int *stream_slots_in_use, int *graph_slots_used)
 {
     int dev = 0;
@@ -1820,7 +1868,7 @@ int rdf_debug_sched_slots(int *stream_slots_in_use, int *graph_slots_used)
     int used = 0;
     for (const auto &kv : g_sched_slot) used += std::get<0>(kv.first) == dev;
     if (stream_slots_in_use) *stream_slots_in_use = used;
-    if (graph_slots_used) *graph_slots_used = g_graph_next[dev];
+    if (graph_slots_used) *graph_slots_used = g_graph_next[dev] - (int)g_graph_free[dev].size();
     return RDF_OK;
 }
 

@@ -212,11 +212,12 @@ class LayeredDecisionForest:
         fused call (a layer filtering on a later layer) run the reference sequence followed by the separate kernels."""
         if self.fused:
             return self._run_fused(depth_image, labels_image, scale_factor, bool(flip_x), color_image)
-        from .cuda.points_ops import PointsOps
-        po = PointsOps()
+        if getattr(self, "_hand_scratch", None) is None:   # once: nothing is allocated per call (or inside a graph capture)
+            from .cuda.points_ops import PointsOps
+            self._hand_scratch = (PointsOps(), GpuBuffer(self.labels_dims, dtype=np.uint16))
+        po, tmp = self._hand_scratch
         ldims = np.array([self.labels_dims[1], self.labels_dims[0]], dtype=np.int32)
         if flip_x:
-            tmp = GpuBuffer(self.labels_dims, dtype=np.uint16)
             self.run(depth_image, tmp, scale_factor)
             po.flip_x(ldims, tmp.cu(), labels_image.cu())
         else:

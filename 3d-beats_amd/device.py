@@ -50,8 +50,14 @@ class HipRuntime:
         return int(handle.data_ptr())
 
     def h2d(self, handle, offset, host_u8):
-        src = self.torch.from_numpy(host_u8)
-        handle[offset:offset + host_u8.size].copy_(src, non_blocking=False)
+        if host_u8.flags.writeable:
+            handle[offset:offset + host_u8.size].copy_(self.torch.from_numpy(host_u8), non_blocking=False)
+            return
+        # a read-only source (a memory-mapped .npy): torch tensors cannot wrap it, so it goes through writable 64-MB pieces
+        step = 1 << 26
+        for a in range(0, host_u8.size, step):
+            piece = np.array(host_u8[a:a + step])
+            handle[offset + a:offset + a + piece.size].copy_(self.torch.from_numpy(piece), non_blocking=False)
 
     def d2h(self, handle, offset, nbytes):
         return handle[offset:offset + nbytes].cpu().numpy()

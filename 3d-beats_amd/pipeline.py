@@ -9,6 +9,9 @@ intermediate buffers and the order.  The reference synchronises the context and 
 depth frame back to the host for the last step (3d_bz.py:461-465, 503-522); here the means and the heights stay
 on the device and ONE small copy (means + heights) ends the frame.
 """
+import ctypes
+import weakref
+
 import numpy as np
 
 from . import _lib
@@ -29,9 +32,12 @@ class HandPipeline:
         # sibling (same forests and tables, own label buffers), so that two pipelines -- the two hands of a frame -- can be
         # in flight together on two streams without overwriting each other's layer-0 labels.  `self.layered_rdf` is the
         # stack this pipeline really runs.
-        if getattr(layered_rdf, "_pipeline_owner", None) is not None:
+        # The mark is a weak reference: a stack whose pipeline is gone serves the next one itself again, and the mark keeps
+        # nothing alive.
+        owner = getattr(layered_rdf, "_pipeline_owner", None)
+        if owner is not None and owner() is not None:
             layered_rdf = layered_rdf.sibling()
-        layered_rdf._pipeline_owner = self
+        layered_rdf._pipeline_owner = weakref.ref(self)
         self.layered_rdf = layered_rdf
         self.DIM_Y, self.DIM_X = int(depth_dims[0]), int(depth_dims[1])
         self.LABELS_REDUCE = int(labels_reduce)
@@ -86,13 +92,23 @@ class HandPipeline:
             self._enqueue(depth_image, depth_image_mm_groups, g_id, flip_x)
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
+        cap_id = ctypes.c_uint64(0)
         with torch.cuda.graph(graph, stream=side):
+            named = self._lib.rdf_stream_capture_id(self._rt.stream(), ctypes.byref(cap_id)) == 0
             self._enqueue(depth_image, depth_image_mm_groups, g_id, flip_x)
+
+        read_fn = self._read
 
         def replay(read=True):
             graph.replay()
-            return self._read() if read else None
-        replay.read = self._read
+            return read_fn() if read else None
+        replay.read = read_fn
+        replay.graph = graph
+        # the recorded forest launches hold tile-queue slots of their own: given back when the replay object is dropped
+        # (the graph goes with it), so that captures over a process's lifetime never run out of them
+        if named:
+            lib, cid = self._lib, int(cap_id.value)
+            replay.release = weakref.finalize(replay, lambda g=graph: (g.reset(), lib.rdf_graph_slots_release(cid)))
         return replay
 
     def _read(self):

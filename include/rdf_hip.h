@@ -150,7 +150,8 @@ int rdf_eval_forest_stats(const uint16_t *depth, int n_img, int dim_x, int dim_y
  * means to the host, divide, add, copy back): all `num_rounds` rounds of all classes run on the device
  * in ONE launch (one workgroup per class), no host round trip, bitwise-reproducible sums (no atomics).
  *   labels     uint16 [dim_y][dim_x]; 0, 65535 and values > num_classes are ignored
- *   variances  float32 [num_classes] (device)
+ *   variances  float32 [num_classes] (device): ALL num_classes entries are read, also those of classes without pixels
+ *              (the reference only reads the entries of labels that occur)
  *   means_out  float64 [num_classes][2] = (x, y) per class (device); NaN for a class without pixels,
  *              as the reference's 0/0
  *   workspace  unused since round 2 (rdf_mean_shift_workspace_bytes() returns 0); may be NULL
@@ -265,7 +266,15 @@ int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream);
  * static tiles). */
 int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved);
 int rdf_stream_destroy(void *stream);
-/* test hook: tile-queue slots of the current device held by streams / handed to launches recorded into hipGraphs */
+/* A forest launch recorded into a hipGraph (stream capture) takes a tile-queue slot of its own -- a graph replays on any
+ * stream -- out of 384 per device; when they are all taken, further captured launches use static tiles (correct, slower on
+ * uneven batches; the library says so once on stderr).  The owner of a graph gives its slots back when the executable graph
+ * is gone: rdf_stream_capture_id(stream, &id) during the capture names it, rdf_graph_slots_release(id) afterwards returns
+ * the number of slots released (0 for an unknown id).  Releasing the slots of a graph that is still replayed is an error
+ * the library cannot see. */
+int rdf_stream_capture_id(void *stream, unsigned long long *capture_id);
+int rdf_graph_slots_release(unsigned long long capture_id);
+/* test hook: tile-queue slots of the current device held by streams / by launches recorded into hipGraphs right now */
 int rdf_debug_sched_slots(int *stream_slots_in_use, int *graph_slots_used);
 /* Peer-to-peer plumbing for the multi-GPU gather (no reference counterpart): a raw device allocation
  * whose 64-byte IPC handle another process of the node opens to get a pointer it can copy into.  rdf_memcpy_device_async
@@ -284,19 +293,21 @@ int rdf_debug_floor_i32(const float *in, int32_t *out, size_t n, void *stream);
 /* Test hook: out[i] = num[i] / den[i] as the kernels compute it (IEEE fp32 divide). */
 int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, void *stream);
 
-/* Tuning knobs (process-wide; 0 restores the default).  Not part of the reference surface. */
+/* Tuning knobs (process-wide atomics, each read once per call; 0 restores the default).  Not part of the reference
+ * surface. */
 void rdf_set_lds_budget_bytes(int bytes);
-void rdf_set_block_threads(int threads); /* 256, 512 or 1024 */
+void rdf_set_block_threads(int threads); /* 256 or 512; anything else: the default (512 for launches that fill the chip) */
 void rdf_set_compaction(int mode);       /* -1 (default): filtered launches list their pixels first; 0: never */
 void rdf_set_scheduler(int mode);        /* 1 dynamic tile queue (default), 0 static round-robin, 2 one tile per
                                            workgroup (non-persistent), -1 env RDF_SCHED = static | tile */
 void rdf_set_rows_per_wave(int rows);    /* label rows per wave in a tile: 1, 2 or 4; 0 = choose by launch size */
-void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (24) */
+void rdf_set_halo(int pixels);           /* depth pixels staged in LDS around a tile; -1 = default (56 with 512-thread
+                                            workgroups at labels_reduce 1, 32 otherwise, 40 for eight trees and more) */
 void rdf_set_tree_waves(int mode);     /* small packed launches of 2-4 trees: one wave per tree and pixel row (k_eval_forest<..., TW>);
                                         * -1 = default (on, or RDF_TREE_WAVES), 0 = off, 1 = on.  Same labels either way. */
 void rdf_set_lds_levels(int levels);     /* top levels of every tree pinned in LDS (the depth tile then gets the rest of
                                             the LDS budget instead of half of it); -1 = fill what the tile leaves */
-void rdf_set_group(int trees);           /* trees a lane walks interleaved: 1..4, 0 = by forest size (256-thread workgroups only) */
+void rdf_set_group(int trees);           /* trees a lane walks interleaved: 1..4, 0 = by forest size (reference-layout forests: 1 or 4) */
 void rdf_set_layers_one_launch(int on);  /* rdf_layered_run on a small launch evaluates the layers of a packed 2- or 3-layer
                                             stack unfiltered in ONE launch and filters in the composite kernel: 1/-1 (default) on, 0 off */
 void rdf_set_stage_vec(int on);          /* tile staging with 16-byte loads where alignment allows: 1/-1 (default) on, 0 off */

@@ -49,6 +49,29 @@ def test_code_object_targets_gfx950(rdf):
     assert b"gfx950" in blob
 
 
+def test_code_object_stays_small(rdf, tmp_path):
+    """Every instantiation of the forest kernel costs compile time and code size; the dispatch in rdf_hip.hip lists the
+    ones launches really take.  Fewer than 60 of them, and a library under 1.5 MB."""
+    import shutil
+    import subprocess
+    from importlib import import_module
+    so = import_module("3d-beats_amd._build").build()
+    assert os.path.getsize(so) < 1_500_000, os.path.getsize(so)
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    local = tmp_path / "lib.so"
+    shutil.copy(so, local)
+    subprocess.check_call([objdump, "--offloading", str(local)], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    kernels = set()
+    for f in os.listdir(tmp_path):
+        if "gfx950" in f:
+            out = subprocess.run([objdump, "-t", str(tmp_path / f)], capture_output=True, text=True).stdout
+            kernels |= {l.split()[-1] for l in out.splitlines()
+                        if "k_eval_forest" in l and " F " in l and not l.split()[-1].endswith(".kd")}
+    assert 0 < len(kernels) < 60, len(kernels)
+
+
 def test_no_gpu_means_loud_failure_not_cpu_fallback(rdf):
     import pytest
     import torch

@@ -791,6 +791,59 @@ def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, tree_waves
         lib.rdf_set_tree_waves(-1)
 
 
+@pytest.mark.parametrize("one_launch", [1, 0])
+def test_filter_class_minus_one_means_no_filter(one_launch, rdf, gpu_runtime, oracle):
+    """A layer that names a filter layer but the filter class -1 is evaluated everywhere (tree_eval.cu:81: the filter is
+    only looked at when filter_class != -1) -- through the one-launch route (the composite kernel applies the filters
+    there) as through filtered launches."""
+    import torch
+    synth = rdf.synth
+    lib = gpu_runtime.lib
+    h, w, r = 240, 424, 2
+    forests = [synth.forest(3, 8, 4, "trained", 300), synth.forest(4, 9, 3, "trained", 310)]
+    conditions = [[0, 1], [0, 2], [1, 4], [0, 3], [0, 4], [0, 5], [0, 6]]
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(forests[0])},
+                      {"model": rdf.DecisionForest.from_numpy(forests[1]), "filter_model": 0, "filter_model_class": -1}],
+           "conditions": conditions, "label_colors": [[i, i, i, 255] for i in range(6)]}
+    lib.rdf_set_layers_one_launch(one_launch)
+    try:
+        lf = rdf.LayeredDecisionForest(cfg, (h, w), r)
+        dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
+        frame = synth.frames(["live"], 955, h, w)[0]
+        dbuf.cu().set(frame)
+        lf.run(dbuf, lbuf, 1.0)
+        shape = (1, h // r, w // r)
+        l0, l1, comp = (np.full(shape, 65535, np.uint16) for _ in range(3))
+        oracle.eval_forest(frame[None], forests[0], l0, r, None, None, 1.0)
+        oracle.eval_forest(frame[None], forests[1], l1, r, None, None, 1.0)     # unfiltered
+        oracle.composite([l0[0], l1[0]], np.array(conditions, np.int32), comp)
+        assert (l1 != 65535).sum() > 1000
+        assert np.array_equal(lf.label_images[0].cu().get(), l0[0])
+        assert np.array_equal(lf.label_images[1].cu().get(), l1[0])
+        assert np.array_equal(lbuf.cu().get(), comp[0])
+    finally:
+        torch.cuda.synchronize()
+        lib.rdf_set_layers_one_launch(-1)
+
+
+@pytest.mark.parametrize("trees", [1, 2, 3, 6])
+def test_small_forests_on_big_batches_take_narrow_walks(trees, rdf, gpu_runtime, oracle):
+    """A batch that fills the chip runs 512-thread workgroups; forests of one, two, three or six trees then walk 1, 2 or 3
+    trees in a lane (no idle slots), packed and from the reference layout: the oracle's labels."""
+    synth = rdf.synth
+    n, h, w = 40, 240, 424
+    f_np = synth.forest(trees, 9, 4, "trained", 400 + trees)
+    frames = synth.frames(["dense", "live"] * (n // 2), 970, h, w)
+    want = np.full(frames.shape, 65535, np.uint16)
+    oracle.eval_forest(frames, f_np, want)
+    forest = rdf.DecisionForest.from_numpy(f_np)
+    depth = rdf.to_device(frames)
+    for packed in (True, False):
+        labels = rdf.DeviceArray(frames.shape, np.uint16).fill(65535)
+        rdf.DecisionTreeEvaluator(use_packed=packed).get_labels_forest(forest, depth, labels)
+        assert np.array_equal(labels.get(), want), (trees, packed)
+
+
 def test_layered_fuzz_against_oracle(rdf, gpu_runtime, oracle):
     """Seeded fuzz over layered stacks: 2-3 layers of random forests (1-9 trees, depth 1-11, 1-18 classes), random
     filter wiring (on any earlier layer or none), reduce, scale, frame size and conditions table; LayeredDecisionForest.run

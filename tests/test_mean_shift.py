@@ -141,3 +141,17 @@ def test_mean_shift_and_heights_in_one_launch_equal_the_two_calls(rdf, gpu_runti
         ms.run_device_with_heights(rounds, dl, L, dv, d_ids, len(ids), dd, r, intr, d_plane, host[1], host[1] + 16 * L)
         torch.cuda.synchronize()
         assert np.array_equal(host[2].view(np.float64).view(np.uint64), got.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_null_labels_are_refused_not_dereferenced(rdf, gpu_runtime):
+    """The one-launch kernel lists every class's pixels whatever the number of rounds: a NULL label image (or variances)
+    is an argument error, also with num_rounds = 0."""
+    lib = gpu_runtime.lib
+    var = rdf.to_device(np.full(4, 10.0, np.float32))
+    means = rdf.DeviceArray((4, 2), np.float64)
+    lab = rdf.to_device(np.zeros((1, 8, 8), np.uint16))
+    assert lib.rdf_mean_shift(None, 8, 8, 4, var.ptr, 0, means.ptr, None, gpu_runtime.stream()) == -2
+    assert lib.rdf_mean_shift(lab.ptr, 8, 8, 4, None, 0, means.ptr, None, gpu_runtime.stream()) == -2
+    assert lib.rdf_mean_shift(lab.ptr, 8, 8, 4, var.ptr, 0, means.ptr, None, gpu_runtime.stream()) == 0
+    assert lib.rdf_mean_shift(None, 0, 8, 4, var.ptr, 0, means.ptr, None, gpu_runtime.stream()) == 0   # no pixel to read

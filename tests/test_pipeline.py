@@ -147,3 +147,58 @@ def test_two_hands_in_flight_together_equal_one_after_the_other(rdf, gpu_runtime
             assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64)), it
             assert np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)), it
         assert np.array_equal(p1.labels_image.cu().get(), lab1) and np.array_equal(p2.labels_image.cu().get(), lab2), it
+
+
+@pytest.mark.gpu
+def test_dropped_replays_give_their_graph_slots_back(rdf, gpu_runtime):
+    """Every forest launch recorded into a hipGraph holds a tile-queue slot of its own (384 per device).  A replay object
+    that is dropped releases its graph and its slots (rdf_graph_slots_release), so capturing again and again -- resolution
+    or configuration changes over a process's lifetime -- never runs the pool dry; a released slot is handed out again."""
+    import ctypes
+    import gc
+    import torch
+    pl = importlib.import_module("3d-beats_amd.pipeline")
+    lib = gpu_runtime.lib
+    depth, groups = _scene(rdf)
+    f0, f1, conditions, colors = _config(rdf)
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(f0)},
+                      {"model": rdf.DecisionForest.from_numpy(f1), "filter_model": 0, "filter_model_class": 3}],
+           "conditions": conditions, "label_colors": colors}
+    lf = rdf.LayeredDecisionForest(cfg, (H, W), R)
+    pipe = pl.HandPipeline(lf, (H, W), R, 1.0, 6, np.full(7, 40., np.float32), [3, 4, 5, 6, 7],
+                           (421.3, 420.9, 423.1, 238.6), np.eye(4, dtype=np.float32))
+    dbuf, gbuf = rdf.GpuBuffer((H, W), np.uint16), rdf.GpuBuffer((H, W), np.uint16)
+    dbuf.cu().set(depth)
+    gbuf.cu().set(groups)
+    want = pipe.run(dbuf, gbuf, 1, False)
+
+    def in_use():
+        used, graph = ctypes.c_int(), ctypes.c_int()
+        assert lib.rdf_debug_sched_slots(ctypes.byref(used), ctypes.byref(graph)) == 0
+        return graph.value
+
+    gc.collect()
+    before = in_use()
+    replay = pipe.capture(dbuf, gbuf, 1, False)
+    held = in_use() - before
+    assert held >= 1
+    got = replay()
+    assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64))
+    del replay, got
+    gc.collect()
+    torch.cuda.synchronize()
+    assert in_use() == before
+    for _ in range(30):          # 30 x `held` slots would not fit next to the others without the release
+        r = pipe.capture(dbuf, gbuf, 1, False)
+        assert in_use() == before + held
+        got = r()
+        assert np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64))
+        del r, got
+        gc.collect()
+    assert in_use() == before
+    # a pipeline that goes away frees its stack for the next one (the owner mark is a weak reference)
+    del pipe
+    gc.collect()
+    pipe2 = pl.HandPipeline(lf, (H, W), R, 1.0, 6, np.full(7, 40., np.float32), [3, 4, 5, 6, 7],
+                            (421.3, 420.9, 423.1, 238.6), np.eye(4, dtype=np.float32))
+    assert pipe2.layered_rdf is lf
