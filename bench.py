@@ -59,12 +59,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline levels "
-                    "then come from the committed profiles/r02_roofline_counters.json and say so)")
+                    "then come from the committed profiles/r03_roofline_counters.json and say so)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the config-5 shard leg (2 GiB forest)")
     ap.add_argument("--cfg5-frames", type=int, default=32)
     ap.add_argument("--cfg5-trees", type=int, default=8, help="(tests shrink the config-5 forest)")
     ap.add_argument("--cfg5-depth", type=int, default=22)
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer variant (pinned H2D + kernel + D2H)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer variant (pinned H2D + kernel + D2H)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs beside the forest kernel (reference-layout "
+                    "forest, trained-like topology, per-hand pipeline, mean shift, training)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed batch (no other legs, no counters): "
                     "what tools/profile.sh traces so that rocprofv3's per-kernel average is the headline kernel's")
     ap.add_argument("--leg", default=None, choices=["headline", "cfg2", "cfg5"],
@@ -144,7 +146,7 @@ def cached(name, make):
 
 def committed_counters(key):
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_counters.json"))).get(key)
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_roofline_counters.json"))).get(key)
     except Exception:
         return None
 
@@ -175,7 +177,7 @@ def roofline_for(leg, key, live, kernel_ms, alg_bytes):
         com = committed_counters(key)
         if com:
             vals, kern = com.get("counters"), com.get("kernel")
-            src = "profiles/r02_roofline_counters.json (committed; this run collected none)"
+            src = "profiles/r03_roofline_counters.json (committed; this run collected none)"
     r = roofline.model(vals, kernel_ms, alg_bytes)
     r["kernel"] = kern or "k_eval_forest"
     r["counters_source"] = src
@@ -371,16 +373,17 @@ def main():
         forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
 
     # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
-    def leg_cfg2(n1):
+    def leg_cfg2(n1, forest_obj=None):
+        forest_obj = forest if forest_obj is None else forest_obj
         one_d, one_l = depth[0:1], rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
         for _ in range(10):
-            ev.get_labels_forest(forest, one_d, one_l)
+            ev.get_labels_forest(forest_obj, one_d, one_l)
         e1 = Events(rt, 2)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         e1.record(0)
         for _ in range(n1):
-            ev.get_labels_forest(forest, one_d, one_l)
+            ev.get_labels_forest(forest_obj, one_d, one_l)
         e1.record(1)
         torch.cuda.synchronize()
         wall1 = (time.perf_counter() - t1) / n1
@@ -516,6 +519,7 @@ def main():
     pix_per_step = world * F * H * W
     value = pix_per_step * a.steps / elapsed / 1e6
     kern_avg_ms = float(np.mean(kern_ms))
+    kern_med_ms = float(np.median(kern_ms))
 
     if a.leg == "headline":
         print(json.dumps({"leg": "headline", "kernel_ms": round(kern_avg_ms, 4), "value": round(value, 2)}), flush=True)
@@ -527,6 +531,9 @@ def main():
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # `value` and `ms_per_step` are the K steps between the two barriers (the bench contract); the median of the K
+        # per-step hipEvent times (SURVEY 8d's protocol) is beside them: this rank's launches, without the gather at N > 1
+        "ms_per_step_median": round(kern_med_ms, 4), "value_median": round(F * H * W / kern_med_ms / 1e3, 2),
         "config": {"workload": f"{F} x {W}x{H} depth frames per GPU per step (config 4 shard = config 2 frame x {F}; "
                                f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
                                + (f"labels gathered to rank 0 ({gather_mode}; control plane {a.backend}) inside the timed region" if world > 1 else "1 GPU"),
@@ -610,8 +617,8 @@ def main():
                                    "the reference's three fills are folded in)"}
 
         # ---- host-buffer variant: pinned H2D of the frames + kernel + D2H of the labels (never `value`) ----
-        if a.pcie:
-            pin_in = torch.from_numpy(frames_np.view(np.int16).reshape(-1)).pin_memory()
+        if not a.no_pcie:
+            pin_in = torch.from_numpy(np.array(frames_np).view(np.int16).reshape(-1)).pin_memory()   # (a writable copy: the cache is memory-mapped read-only)
             pin_out = torch.empty(F * H * W, dtype=torch.int16).pin_memory()
             d_t, l_t = depth.torch_bytes().view(torch.int16), labels.torch_bytes().view(torch.int16)
             for rep in range(4):
@@ -673,21 +680,34 @@ def main():
             from oracle import rdf_oracle  # the checker; never the thing measured as `value`
             got = labels.get()
             cores = min(host_cores(), rdf_oracle.max_threads())
-            done, t_cpu, mism = 0, 0.0, 0
+            # (i) parity: every frame of the timed step against the oracle (bounded by --cpu-seconds)
+            done, t_par, mism = 0, 0.0, 0
             for i in range(F):      # the batch alternates dense / live-like frames
                 want = np.full((1, H, W), 65535, np.uint16)
                 tc = time.perf_counter()
                 rdf_oracle.eval_forest(frames_np[i:i + 1], forest_np, want, n_threads=cores)
-                t_cpu += time.perf_counter() - tc
+                t_par += time.perf_counter() - tc
                 mism += int((want[0] != got[i]).sum())
                 done += 1
-                if t_cpu >= a.cpu_seconds:
+                if t_par >= a.cpu_seconds:
                     break
-            out["cpu_baseline"] = {"value": round(done * H * W / t_cpu / 1e6, 3), "unit": "Mpix/s", "cores": cores,
+            # (ii) the baseline figure: median of 5 passes over a FIXED sample, the step's first 8 frames (4 dense, 4 live-like)
+            ns = min(8, F)
+            want8 = np.full((ns, H, W), 65535, np.uint16)
+            passes = []
+            for _ in range(5):
+                want8[:] = 65535
+                tc = time.perf_counter()
+                rdf_oracle.eval_forest(frames_np[0:ns], forest_np, want8, n_threads=cores)
+                passes.append(time.perf_counter() - tc)
+            mism += int((want8 != got[0:ns]).sum())
+            t_med = float(np.median(passes))
+            out["cpu_baseline"] = {"value": round(ns * H * W / t_med / 1e6, 3), "unit": "Mpix/s", "cores": cores,
                                    "kind": "port",
-                                   "sample": f"{done} of the step's {F} frames (alternating dense/live-like), "
-                                             f"{t_cpu:.1f} s of oracle/rdf_oracle.c (OpenMP, -O2) on the host; "
-                                             f"GPU labels of those frames differ in {mism} pixels"}
+                                   "sample": f"median of 5 passes over the step's first {ns} frames (alternating dense/live-like), "
+                                             f"{t_med:.2f} s per pass of oracle/rdf_oracle.c (OpenMP, -O2) on the host; parity: "
+                                             f"{done} of the step's {F} frames checked in {t_par:.1f} s, GPU labels differ in {mism} pixels",
+                                   "passes_s": [round(x, 3) for x in passes], "parity_frames": done, "differing_pixels": mism}
             assert mism == 0, f"GPU labels differ from the oracle in {mism} pixels"
             # what a "numpy fallback" would have been (variant ii): level-synchronous numpy, one process
             from oracle import rdf_numpy
@@ -698,6 +718,71 @@ def main():
             out["cpu_baseline_numpy"] = {"value": round(H * W / tn / 1e6, 3), "unit": "Mpix/s", "cores": 1,
                                          "kind": "port", "sample": f"1 live-like frame, {tn:.1f} s of oracle/rdf_numpy.py; "
                                          f"labels differ from the GPU's in {int((wn[0] != got[1]).sum())} pixels"}
+
+        # ---- the legs beside the packed forest kernel, each with its own in-run check; a leg that fails becomes a field ----
+        def leg(name, fn):
+            t_leg = time.perf_counter()
+            try:
+                out[name] = fn()
+            except Exception as e:   # noqa: BLE001 -- the headline must still be printed
+                out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            out[name]["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+
+        def leg_unpacked():
+            """The same batch straight from the reference-layout forest (the .npy as it is, no rdf_forest_pack)."""
+            ev_u = rdf.DecisionTreeEvaluator(use_packed=False)
+            lab_u = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
+            for _ in range(2):
+                ev_u.get_labels_forest(forest, depth, lab_u)
+            eu = Events(rt, 10)
+            for i in range(5):
+                eu.record(2 * i)
+                ev_u.get_labels_forest(forest, depth, lab_u)
+                eu.record(2 * i + 1)
+            ms_u = float(np.median([eu.elapsed_ms(2 * i, 2 * i + 1) for i in range(5)]))
+            eu.destroy()
+            same = bool(np.array_equal(lab_u.get(), scratch.get()))
+            assert same, "reference-layout path and packed path disagree"
+            return {"value": round(F * H * W / ms_u / 1e3, 2), "unit": "Mpix/s", "ms_per_step": round(ms_u, 4), "steps": 5,
+                    "labels_equal_packed_path": same, "what": "rdf_eval_forest on the reference's float32 [T][2^D-1][7+2C] records"}
+
+        def leg_trained():
+            """Config 2 with the trained-like topology (15 % of the sides become leaves per level from level 3 on; PDFs =
+            normalised counts): one dense frame per launch, the batch rate, and frames checked against the oracle."""
+            from oracle import rdf_oracle
+            ft_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_trained", lambda: synth.forest(T, D, C, "trained")))
+            ft = rdf.DecisionForest.from_numpy(ft_np)
+            ft.packed(1.0)
+            res = leg_cfg2(200, ft)
+            lab_t = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
+            for _ in range(2):
+                ev.get_labels_forest(ft, depth, lab_t)
+            et = Events(rt, 20)
+            for i in range(10):
+                et.record(2 * i)
+                ev.get_labels_forest(ft, depth, lab_t)
+                et.record(2 * i + 1)
+            ms_t = float(np.median([et.elapsed_ms(2 * i, 2 * i + 1) for i in range(10)]))
+            et.destroy()
+            ns = min(8, F)
+            want = np.full((ns, H, W), 65535, np.uint16)
+            st = np.zeros(3, np.uint64)
+            rdf_oracle.eval_forest(frames_np[0:ns], ft_np, want, n_threads=min(host_cores(), rdf_oracle.max_threads()), stats=st)
+            mism = int((want != lab_t[0:ns].get()).sum())
+            assert mism == 0, f"trained-like topology: GPU labels differ from the oracle in {mism} pixels"
+            res.update({"topology": "trained", "batch": {"value": round(F * H * W / ms_t / 1e3, 2), "unit": "Mpix/s",
+                                                          "ms_per_step": round(ms_t, 4), "frames": F, "steps": 10},
+                        "mean_levels_per_pixel_and_tree": round(float(st[1]) / max(1.0, float(st[0]) * T), 2),
+                        "parity": {"frames_checked": ns, "differing_pixels": mism, "checker": "oracle/rdf_oracle.c on the host"}})
+            return res
+
+        if not a.no_extra_legs:
+            import bench_legs
+            leg("unpacked", leg_unpacked)
+            leg("cfg2_trained", leg_trained)
+            leg("hand_pipeline", lambda: bench_legs.hand_pipeline(rdf))
+            leg("mean_shift", lambda: bench_legs.mean_shift(rdf))
+            leg("train", lambda: bench_legs.train(rdf))
 
         # ---- config 5's shard last: it frees the headline's buffers first (2 GiB forest + 2.5 GiB packed tables) ----
         if not a.no_cfg5:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py's JSON line -> profiles/<tag>_bench.json (the line, pretty-printed) and profiles/r02_roofline_counters.json
+"""bench.py's JSON line -> profiles/<tag>_bench.json (the line, pretty-printed) and profiles/r03_roofline_counters.json
 (the counters of its three --pmc legs: what bench.py falls back to when a run cannot collect counters itself).
 usage: tools/save_profile.py gpurun_out/<dir>/bench.json <tag>"""
 import json
@@ -25,8 +25,8 @@ def main(path, tag):
         out[key] = {"kernel": r["kernel"], "counters": r["counters"], "kernel_ms_of_that_run": r["kernel_ms"],
                     "collected_by": f"bench.py's rocprofv3 --pmc child passes ({tag})"}
     if out:
-        json.dump(out, open(os.path.join(ROOT, "profiles", "r02_roofline_counters.json"), "w"), indent=1)
-    print(f"saved profiles/{tag}_bench.json" + (", profiles/r02_roofline_counters.json" if out else ""))
+        json.dump(out, open(os.path.join(ROOT, "profiles", "r03_roofline_counters.json"), "w"), indent=1)
+    print(f"saved profiles/{tag}_bench.json" + (", profiles/r03_roofline_counters.json" if out else ""))
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ rdf_hip.hip to ISA text, takes the innermost loop of one instantiation of k_eval
 the blocks of the IEEE-divide path (they run only for nodes flagged kFlagExact) and counts the instructions of each
 class.  Its `half_rate_share` is tools/roofline.py's VALU_HALF_RATE_SHARE.
 
-    python3 tools/valu_mix.py [mangled-name substring, default: the packed 256-thread 4-tree kernel]
+    python3 tools/valu_mix.py [mangled-name substring, default: the packed 512-thread 4-tree kernel of the bench batch]
 """
 import collections
 import json
@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "3d-beats_amd", "csrc", "rdf_hip.hip")
 FULL_RATE = {"v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_add_u32", "v_sub_u32",
              "v_subrev_u32", "v_mov_b32"}
-EXACT_PATH_MARKS = ("v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_rcp_f32")
+# blocks of the IEEE-divide path: the divide itself, the fetch of the exact record (64-bit addressed), the mode switches
+EXACT_PATH_MARKS = ("v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_rcp_f32", "v_lshl_add_u64", "s_setreg_imm32_b32")
 
 
 def isa_text():
@@ -64,4 +65,4 @@ def main(sub):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "k_eval_forestILi256ELb1ELi4ELb0ELb1ELi4ELb0E")
+    main(sys.argv[1] if len(sys.argv) > 1 else "k_eval_forestILi512ELb1ELi4ELb0ELi4ELb0ELi1ELb0E")
