@@ -131,48 +131,80 @@ class ShardedForestEvaluator:
 
 
 class PeerCopyGather:
-    """Receive buffer on rank `dst`, mapped into every process of the node.  Collective constructor.
+    """Receive RING on rank `dst`, mapped into every process of the node.  Collective constructor.
+
+    Layout of rank dst's allocation: n_slots x world x bytes_per_rank bytes of label maps -- step s of rank g lands in
+    slot s % n_slots at [slot][g] -- followed by two arrays of uint64 counters, 64 bytes apart:
+      ready[slot][g]    = s + 1 once rank g's copy of step s has landed (written by rank g with a second copy on the same
+                          stream, i.e. after the data);
+      consumed[slot]    = s + 1 once the consumer on rank dst has released step s (`release`).
+    A consumer on rank dst calls wait_ready(s) (all world counters of the slot show s + 1), reads slot_array(s), then
+    release(s); a producer that is about to reuse a slot waits for consumed[slot] >= s - n_slots + 1 first when flow control
+    is on (PeerCopyForestEvaluator(flow_control=True)).  With two slots a consumer has one whole step to read.
 
     `ok` is False on every rank if any rank could not map the buffer (no IPC between the processes, e.g. devices hidden
-    from each other): callers then fall back to the RCCL gather."""
+    from each other) or if anything else went wrong on any rank -- `errors` then holds every rank's reason -- and callers
+    fall back to the RCCL gather.  No rank raises out of the constructor before every collective has been entered by
+    every rank."""
 
-    def __init__(self, world, rank, bytes_per_rank, dst=0, group=None, _fail_open_on_rank=None):
+    FLAG_STRIDE = 64
+
+    def __init__(self, world, rank, bytes_per_rank, dst=0, group=None, n_slots=2, _fail_open_on_rank=None):
         import torch
         import torch.distributed as dist
         self._lib = get_runtime().lib
+        self.torch = torch
         self.world, self.rank, self.dst, self.bytes_per_rank = int(world), int(rank), int(dst), int(bytes_per_rank)
+        self.n_slots = max(1, int(n_slots))
+        self.data_bytes = self.n_slots * self.world * self.bytes_per_rank
+        self.data_bytes_aligned = (self.data_bytes + 255) & ~255
+        self.flag_bytes = self.n_slots * (self.world + 1) * self.FLAG_STRIDE
         self.base = None          # device pointer of the whole receive buffer as seen from THIS process
         self._owned, self._mapped = None, None
+        self.errors = None
+        # counters are read and written with small copies on a stream of their own (torch streams do not synchronise with the
+        # default stream), so a poll never queues behind a forest launch; values come from a device table (index = value - 1)
+        self._poll_stream = torch.cuda.Stream()
+        self._host8 = torch.zeros(max(self.world + 1, 8) * self.n_slots * (self.FLAG_STRIDE // 8), dtype=torch.int64).pin_memory()
+        self._vals_base, self._vals = 0, torch.arange(1, 65537, dtype=torch.int64, device="cuda")
+        self._old_vals = []
         handle = [None]
-        mine_ok = 1
-        if self.rank == self.dst:
-            p = ctypes.c_void_p()
-            rc = self._lib.rdf_device_malloc(ctypes.byref(p), self.world * self.bytes_per_rank)
-            buf = ctypes.create_string_buffer(64)
-            if rc == 0:
-                self._owned = p.value
-                rc = self._lib.rdf_ipc_export(p, buf)
-            if rc == 0:
-                handle[0] = bytes(buf.raw)
-                self.base = self._owned
-            else:
-                mine_ok = 0
-        dist.broadcast_object_list(handle, src=self.dst, group=group)
-        if self.rank != self.dst:
-            if handle[0] is None:
-                mine_ok = 0
-            else:
+        mine_ok, why = 1, None
+        try:
+            if self.rank == self.dst:
                 p = ctypes.c_void_p()
-                rc = self._lib.rdf_ipc_open(ctypes.create_string_buffer(handle[0], 64), ctypes.byref(p))
-                if _fail_open_on_rank == self.rank:       # test hook: behave as if this rank could not map the buffer
-                    if rc == 0:
-                        self._lib.rdf_ipc_close(p)
-                    rc = -1
+                rc = self._lib.rdf_device_malloc(ctypes.byref(p), self.data_bytes_aligned + self.flag_bytes)
+                buf = ctypes.create_string_buffer(64)
                 if rc == 0:
-                    self._mapped = p.value
-                    self.base = self._mapped
+                    self._owned = p.value
+                    rc = self._lib.rdf_ipc_export(p, buf)
+                if rc == 0:
+                    handle[0] = bytes(buf.raw)
+                    self.base = self._owned
                 else:
-                    mine_ok = 0
+                    mine_ok, why = 0, f"hipMalloc / hipIpcGetMemHandle: {self._err(rc)}"
+        except Exception as e:      # noqa: BLE001 -- a rank that fails here must still reach the collectives below
+            mine_ok, why = 0, repr(e)
+        dist.broadcast_object_list(handle, src=self.dst, group=group)
+        try:
+            if self.rank != self.dst:
+                if handle[0] is None:
+                    mine_ok, why = 0, "rank dst exported no handle"
+                else:
+                    p = ctypes.c_void_p()
+                    rc = self._lib.rdf_ipc_open(ctypes.create_string_buffer(handle[0], 64), ctypes.byref(p))
+                    if _fail_open_on_rank == self.rank:       # test hook: behave as if this rank could not map the buffer
+                        if rc == 0:
+                            self._lib.rdf_ipc_close(p)
+                        rc = -1
+                    if rc == 0:
+                        self._mapped = p.value
+                        self.base = self._mapped
+                    else:
+                        mine_ok, why = 0, f"hipIpcOpenMemHandle: {'refused by the test hook' if rc == -1 else self._err(rc)}"
+        except Exception as e:      # noqa: BLE001
+            mine_ok, why = 0, repr(e)
+
         def all_ok(v):
             flag = torch.tensor([v], dtype=torch.int32)
             if dist.get_backend(group) == "nccl":
@@ -182,36 +214,158 @@ class PeerCopyGather:
 
         self.ok = all_ok(mine_ok)
         if self.ok:
-            # end-to-end check before anything relies on it: every rank copies a pattern into its slot, rank dst reads
-            # all of them back
-            n = min(256, self.bytes_per_rank)
-            pattern = torch.full((n,), 17 + self.rank, dtype=torch.uint8, device="cuda")
-            rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self.slot_ptr(self.rank)), ctypes.c_void_p(pattern.data_ptr()),
-                                                   n, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-            torch.cuda.synchronize()
-            copied = all_ok(1 if rc == 0 else 0)      # (also a barrier: every pattern has landed)
+            # end-to-end check before anything relies on it: every rank copies a pattern into its slot and raises its ready
+            # counter, rank dst reads all of them back
+            rc, n = -1, min(256, self.bytes_per_rank)
+            try:
+                if self.rank == self.dst:
+                    self._flags_tensor().zero_()
+                    torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                why = repr(e)
+            zeroed = all_ok(1 if why is None else 0)      # (also a barrier: the counters are zero before anyone writes)
+            try:
+                if zeroed:
+                    pattern = torch.full((n,), 17 + self.rank, dtype=torch.uint8, device="cuda")
+                    st = torch.cuda.current_stream().cuda_stream
+                    rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self.slot_ptr(self.rank)), ctypes.c_void_p(pattern.data_ptr()),
+                                                           n, ctypes.c_void_p(st))
+                    if rc == 0:
+                        rc = self._signal(0, 0, st, value=0xA5)
+                    torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                rc, why = -1, repr(e)
+            if rc != 0 and why is None:
+                why = f"peer copy: {self._err(rc)}"
+            copied = zeroed and all_ok(1 if rc == 0 else 0)      # (also a barrier: every pattern has landed)
             seen = 1
-            if copied and self.rank == self.dst:
-                got = self.result_array().view(self.world, self.bytes_per_rank)[:, :n].cpu()
-                want = (17 + torch.arange(self.world, dtype=torch.uint8)).view(-1, 1).expand(self.world, n)
-                seen = 1 if bool((got == want).all()) else 0
+            try:
+                if copied and self.rank == self.dst:
+                    got = self.result_array().view(self.n_slots, self.world, self.bytes_per_rank)[0, :, :n].cpu()
+                    want = (17 + torch.arange(self.world, dtype=torch.uint8)).view(-1, 1).expand(self.world, n)
+                    flags = self.ready_counters()[0]
+                    seen = 1 if bool((got == want).all()) and bool((flags == 0xA5).all()) else 0
+                    if not seen:
+                        why = "pattern or ready counters did not arrive"
+                    self._flags_tensor().zero_()
+                    torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                seen, why = 0, repr(e)
             self.ok = copied and all_ok(seen)
+        reasons = [None] * self.world
+        dist.all_gather_object(reasons, why, group=group)
         if not self.ok:
+            self.errors = {g: r for g, r in enumerate(reasons) if r} or {"?": "a rank reported failure without a reason"}
             self.close()
 
-    def slot_ptr(self, rank, byte_offset=0):
-        return self.base + rank * self.bytes_per_rank + byte_offset
+    def _err(self, rc):
+        msg = self._lib.rdf_error_string(int(rc))
+        return (msg.decode() if isinstance(msg, bytes) else str(msg)) + f" (code {rc})"
 
-    def result_array(self):
-        """Rank `dst`: the receive buffer as a torch uint8 tensor (zero copy)."""
-        import torch
+    # -- layout ------------------------------------------------------------------------------------
+    def slot_ptr(self, rank, byte_offset=0, step=0):
+        return self.base + ((int(step) % self.n_slots) * self.world + rank) * self.bytes_per_rank + byte_offset
 
+    def _ready_ptr(self, step, rank):
+        return self.base + self.data_bytes_aligned + ((int(step) % self.n_slots) * (self.world + 1) + rank) * self.FLAG_STRIDE
+
+    def _consumed_ptr(self, step):
+        return self._ready_ptr(step, self.world)
+
+    def _flags_tensor(self):
+        """Rank dst: the counters as a torch int64 tensor [n_slots, world + 1, FLAG_STRIDE / 8] (zero copy)."""
+        return self._view(self._owned + self.data_bytes_aligned, self.flag_bytes).view(self.torch.int64).view(
+            self.n_slots, self.world + 1, self.FLAG_STRIDE // 8)
+
+    def _view(self, ptr, nbytes):
         class _View:
             pass
         v = _View()
-        v.__cuda_array_interface__ = {"shape": (self.world * self.bytes_per_rank,), "typestr": "|u1",
-                                      "data": (self._owned, False), "version": 2}
-        return torch.as_tensor(v, device="cuda")
+        v.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return self.torch.as_tensor(v, device="cuda")
+
+    def _value_ptr(self, value):
+        """Device address of an int64 that holds `value` (>= 1): the source of a counter update by device-to-device copy."""
+        value = int(value)
+        if not (self._vals_base < value <= self._vals_base + self._vals.numel()):
+            self._old_vals = (self._old_vals + [self._vals])[-2:]      # (copies in flight may still read the old table)
+            self._vals_base = ((value - 1) // 65536) * 65536
+            self._vals = self.torch.arange(self._vals_base + 1, self._vals_base + 65537, dtype=self.torch.int64, device="cuda")
+            self.torch.cuda.synchronize()
+        return self._vals.data_ptr() + 8 * (value - 1 - self._vals_base)
+
+    def _signal(self, step, which_rank_slot, stream, value=None):
+        """Stream-ordered: this rank's ready counter of `step`'s slot := step + 1 (a second small copy behind the data)."""
+        return self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self._ready_ptr(step, self.rank)),
+                                                 ctypes.c_void_p(self._value_ptr(int(step) + 1 if value is None else value)),
+                                                 8, ctypes.c_void_p(stream))
+
+    def _peek(self, ptr, n_words):
+        """n_words int64 at device address `ptr`, read now (own stream), as a list."""
+        st = ctypes.c_void_p(self._poll_stream.cuda_stream)
+        rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self._host8.data_ptr()), ctypes.c_void_p(ptr), 8 * n_words, st)
+        _lib.check(self._lib, rc, "rdf_memcpy_device_async (counters)")
+        _lib.check(self._lib, self._lib.rdf_stream_synchronize(st), "rdf_stream_synchronize")
+        return self._host8[:n_words].tolist()
+
+    # -- producer side -----------------------------------------------------------------------------
+    def push(self, step, src_ptr, nbytes, stream):
+        """Copy this rank's label maps of `step` into its place in the ring and raise the ready counter behind them; both
+        on `stream` (copy engines; nothing runs on a CU)."""
+        rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self.slot_ptr(self.rank, 0, step)), ctypes.c_void_p(src_ptr), int(nbytes),
+                                               ctypes.c_void_p(stream))
+        _lib.check(self._lib, rc, "rdf_memcpy_device_async (label maps)")
+        _lib.check(self._lib, self._signal(step, self.rank, stream), "rdf_memcpy_device_async (ready counter)")
+
+    def wait_free(self, step, timeout_s=30.0, poll_s=50e-6):
+        """Producer: block (host) until the consumer has released the step that last used `step`'s slot."""
+        import time
+        need = int(step) - self.n_slots + 1
+        if need <= 0:
+            return True
+        t0 = time.perf_counter()
+        while True:
+            if self._peek(self._consumed_ptr(step), 1)[0] >= need:
+                return True
+            if time.perf_counter() - t0 > timeout_s:
+                return False
+            time.sleep(poll_s)
+
+    # -- consumer side (rank dst) ------------------------------------------------------------------
+    def ready_counters(self):
+        """Rank dst: int64 [n_slots, world] on the host."""
+        words = self.FLAG_STRIDE // 8
+        flat = self._peek(self._owned + self.data_bytes_aligned, self.n_slots * (self.world + 1) * words)
+        t = self.torch.tensor(flat, dtype=self.torch.int64).view(self.n_slots, self.world + 1, words)
+        return t[:, :self.world, 0]
+
+    def is_ready(self, step):
+        return bool((self.ready_counters()[int(step) % self.n_slots] >= int(step) + 1).all())
+
+    def wait_ready(self, step, timeout_s=30.0, poll_s=50e-6):
+        """Rank dst: block (host) until every rank's label maps of `step` have landed in the ring."""
+        import time
+        t0 = time.perf_counter()
+        while not self.is_ready(step):
+            if time.perf_counter() - t0 > timeout_s:
+                return False
+            time.sleep(poll_s)
+        return True
+
+    def release(self, step):
+        """Rank dst: the consumer is done with `step`; its slot may be overwritten (by step + n_slots)."""
+        st = ctypes.c_void_p(self._poll_stream.cuda_stream)
+        rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self._consumed_ptr(step)), ctypes.c_void_p(self._value_ptr(int(step) + 1)), 8, st)
+        _lib.check(self._lib, rc, "rdf_memcpy_device_async (consumed counter)")
+        _lib.check(self._lib, self._lib.rdf_stream_synchronize(st), "rdf_stream_synchronize")
+
+    def slot_array(self, step):
+        """Rank dst: step `step`'s label maps of all ranks, torch uint8 [world, bytes_per_rank] (zero copy)."""
+        return self.result_array().view(self.n_slots, self.world, self.bytes_per_rank)[int(step) % self.n_slots]
+
+    def result_array(self):
+        """Rank `dst`: the whole ring as a torch uint8 tensor [n_slots * world * bytes_per_rank] (zero copy)."""
+        return self._view(self._owned, self.data_bytes)
 
     def close(self):
         if self._mapped is not None:
@@ -224,10 +378,12 @@ class PeerCopyGather:
 
 
 class PeerCopyForestEvaluator:
-    """One launch per step; each rank copies its label maps into rank `dst`'s buffer on a side stream, so the copy
-    of step s overlaps the launch of step s+1 (two label buffers used alternately, as in step_overlapped)."""
+    """One launch per step; each rank copies its label maps into rank `dst`'s ring on a side stream, so the copy
+    of step s overlaps the launch of step s+1 (two label buffers used alternately, as in step_overlapped).  With
+    flow_control the producer waits (host side, before it reuses a ring slot) until the consumer on rank dst has released
+    the step that used the slot before: PeerCopyGather.wait_ready / slot_array / release are the consumer's side."""
 
-    def __init__(self, evaluator, forest, frames_per_rank, depth_dims, gather, labels_reduce=1, scale_factor=1.):
+    def __init__(self, evaluator, forest, frames_per_rank, depth_dims, gather, labels_reduce=1, scale_factor=1., flow_control=False):
         import torch
         self.torch = torch
         self.ev, self.forest, self.gather = evaluator, forest, gather
@@ -238,8 +394,13 @@ class PeerCopyForestEvaluator:
         assert self.nbytes == gather.bytes_per_rank
         self._lib = get_runtime().lib
         self.copy_stream = torch.cuda.Stream()
+        self.flow_control = bool(flow_control)
         self._copied = {}
         self._step_no = 0
+
+    @property
+    def steps_done(self):
+        return self._step_no
 
     def step(self, depth, labels_ring, prefill=None):
         torch = self.torch
@@ -254,11 +415,10 @@ class PeerCopyForestEvaluator:
         self.ev.get_labels_forest(self.forest, depth, labels, labels_reduce=self.r, scale_factor=self.s)
         done = torch.cuda.Event()
         done.record(cur)
+        if self.flow_control and not self.gather.wait_free(self._step_no):
+            raise _lib.RdfError(f"rank {self.gather.rank}: the consumer never released the ring slot of step {self._step_no}")
         self.copy_stream.wait_event(done)
-        rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self.gather.slot_ptr(self.gather.rank)),
-                                               ctypes.c_void_p(labels.ptr), self.nbytes,
-                                               ctypes.c_void_p(self.copy_stream.cuda_stream))
-        _lib.check(self._lib, rc, "rdf_memcpy_device_async")
+        self.gather.push(self._step_no, labels.ptr, self.nbytes, self.copy_stream.cuda_stream)
         ev = torch.cuda.Event()
         ev.record(self.copy_stream)
         self._copied[slot] = ev
@@ -269,8 +429,10 @@ class PeerCopyForestEvaluator:
         """This rank's copies have landed.  (Rank dst may read after a barrier that follows every rank's drain.)"""
         self.copy_stream.synchronize()
 
-    def result(self):
-        """Rank dst: DeviceArray-like torch view [world*frames, lh, lw] of uint16 as int16 bytes; else None."""
+    def result(self, step=None):
+        """Rank dst: torch view [world*frames, lh, lw] (uint16 bits as int16) of one step's label maps -- the last step by
+        default; else None."""
         if self.gather.rank != self.gather.dst:
             return None
-        return self.gather.result_array().view(self.torch.int16).view(self.gather.world * self.frames, self.lh, self.lw)
+        step = self._step_no - 1 if step is None else int(step)
+        return self.gather.slot_array(max(step, 0)).view(self.torch.int16).view(self.gather.world * self.frames, self.lh, self.lw)

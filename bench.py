@@ -78,11 +78,14 @@ def parse():
                          "but a concurrent RCCL kernel never waits for a free slot)")
     ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl", "both"],
                     help="how the label maps reach rank 0 at N>1: p2p = every rank copies its shard into rank 0's "
-                         "IPC-mapped buffer with the copy engines (no CU involved); rccl = torch.distributed.gather on a "
-                         "compute stream that leaves 32 CUs to RCCL; auto = p2p if the buffer can be mapped, else rccl; "
-                         "both = time p2p and rccl back to back (`value` is p2p's, `gather_modes` carries both)")
+                         "IPC-mapped ring with the copy engines (no CU involved); rccl = torch.distributed.gather on a "
+                         "compute stream that leaves 32 CUs to RCCL; "
+                         "auto (default) = time both back to back, `value` is the faster one's and `gather_modes` carries both "
+                         "(rccl alone if the buffer cannot be mapped); both = the same, but `value` is p2p's")
     ap.add_argument("--reserve-cus", type=int, default=-1, help="run the forest kernel on a stream that leaves this many CUs "
                     "(one per shader engine = 32) to RCCL's kernels; -1: 32 with the rccl gather, 0 otherwise (DESIGN.md section 6)")
+    ap.add_argument("--fail-ipc-open-on-rank", type=int, default=None, help="test hook: that rank behaves as if it could not map "
+                    "rank 0's receive buffer (the run must fall back to the RCCL gather and say why)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
                     "rehearse the control flow with several ranks on one GPU)")
     return ap.parse_args()
@@ -406,13 +409,13 @@ def main():
 
     # N>1, default: peer copies over xGMI by the copy engines (RCCL carries only the control plane); needs HIP IPC
     # between the ranks' processes, falls back to the RCCL gather if any rank cannot map rank 0's buffer
-    peer, pg = None, None
+    peer, pg, notes = None, None, {}      # notes: what was unavailable on this run and why (goes on the N > 1 line)
     if world > 1 and a.chunks == 0 and a.gather in ("auto", "p2p", "both"):
-        pg = dmod.PeerCopyGather(world, rank, F * H * W * 2)
+        pg = dmod.PeerCopyGather(world, rank, F * H * W * 2, _fail_open_on_rank=a.fail_ipc_open_on_rank)
         if pg.ok:
             peer = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg)
-        elif a.gather == "p2p":
-            sys.exit("--gather p2p: rank 0's receive buffer could not be mapped by every rank")
+        else:
+            notes["p2p"] = "unavailable: " + "; ".join(f"rank {g}: {why}" for g, why in (pg.errors or {}).items())
 
     # ---- algorithmic bytes of one step, from the visit counters of the same walk ----
     dstats = rdf.DeviceArray((3,), np.uint64).fill(0)
@@ -428,14 +431,33 @@ def main():
     def masked_stream(reserve):
         import ctypes
         h = ctypes.c_void_p()
-        rc_m = lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), reserve)
-        if rc_m != 0:
-            print(f"rank {rank}: no CU-masked stream ({lib.rdf_error_string(rc_m)}); using the current stream", file=sys.stderr)
-            return None, None
-        return h, torch.cuda.ExternalStream(h.value)
+        try:
+            rc_m = lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), reserve)
+            why = None if rc_m == 0 else str(lib.rdf_error_string(rc_m))
+            st_m = torch.cuda.ExternalStream(h.value) if rc_m == 0 else None
+        except Exception as e:   # noqa: BLE001
+            why, st_m = repr(e), None
+        if st_m is None:
+            print(f"rank {rank}: no CU-masked stream ({why}); using the current stream", file=sys.stderr)
+            return None, None, why
+        return h, st_m, None
 
-    def timed(step_fn, drain_fn, stream):
-        """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
+    def timed(step_fn_raw, drain_fn_raw, stream):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks.  A step that
+        raises on this rank stops doing work but the rank keeps walking through every barrier, so that the other ranks are
+        not left waiting; the mode is then reported as failed (third return value) on every rank."""
+        failure = []
+
+        def guarded(fn):
+            def run():
+                if failure:
+                    return
+                try:
+                    fn()
+                except Exception as e:   # noqa: BLE001
+                    failure.append(f"rank {rank}: {type(e).__name__}: {e}"[:300])
+            return run
+        step_fn, drain_fn = guarded(step_fn_raw), guarded(drain_fn_raw)
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         with ctx:
             for _ in range(a.warmup):
@@ -453,11 +475,18 @@ def main():
             elapsed = time.perf_counter() - t0
             kms = [evs.elapsed_ms(2 * i, 2 * i + 1) for i in range(a.steps)]
             evs.destroy()
+        failed = None
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, kms
+            why = [None] * world
+            dist.all_gather_object(why, failure[0] if failure else None)
+            if any(why):
+                failed = "; ".join(w for w in why if w)
+        elif failure:
+            raise RuntimeError(failure[0])
+        return elapsed, kms, failed
 
     def gather_check(result_fn, from_peer):
         """Did rank 0 really receive every rank's label maps?  (checksum of checksums)"""
@@ -478,27 +507,61 @@ def main():
 
     modes = {}          # name -> (step, drain, stream, reserve, result_fn, from_peer)
     handles = []
+
+    def rccl_mode():
+        reserve = a.reserve_cus if a.reserve_cus >= 0 else 32
+        h, st, why = masked_stream(reserve) if reserve > 0 else (None, None, None)
+        if why:
+            notes["cu_masked_stream"] = f"unavailable: {why}"
+        handles.append(h)
+        step = (lambda: sharded.step_overlapped(depth, ring)) if overlapped else (lambda: sharded.step(depth, labels))
+        return (step, sharded.drain, st, reserve if st is not None else 0, sharded.result, False)
+
     if world == 1:
         modes["none"] = (lambda: sharded.step(depth, labels), sharded.drain, None, 0, None, False)
     else:
-        if peer is not None:
+        if peer is not None and a.gather != "rccl":
             modes["p2p copy engines"] = (lambda: peer.step(depth, ring), peer.drain, None, 0, peer.result, True)
-        if peer is None or a.gather in ("rccl", "both"):
-            reserve = a.reserve_cus if a.reserve_cus >= 0 else 32
-            h, st = masked_stream(reserve) if reserve > 0 else (None, None)
-            handles.append(h)
-            step = (lambda: sharded.step_overlapped(depth, ring)) if overlapped else (lambda: sharded.step(depth, labels))
-            modes["rccl gather"] = (step, sharded.drain, st, reserve if st is not None else 0, sharded.result, False)
-        if a.gather == "rccl" and "p2p copy engines" in modes:
-            del modes["p2p copy engines"]
+        if "p2p copy engines" not in modes or a.gather in ("rccl", "both", "auto"):
+            modes["rccl gather"] = rccl_mode()
     torch.cuda.synchronize()
 
-    results = {}
-    for name, (step, drain, st, reserve, result_fn, from_peer) in modes.items():
-        elapsed, kms = timed(step, drain, st)
-        results[name] = {"elapsed": elapsed, "kern_ms": kms, "reserve": reserve,
-                         "gather_check": gather_check(result_fn, from_peer) if world > 1 else None}
+    results, failed_modes = {}, {}
+    queue = list(modes.items())
+    while queue:
+        name, (step, drain, st, reserve, result_fn, from_peer) = queue.pop(0)
+        elapsed, kms, failed = timed(step, drain, st)
+        if failed is None and world > 1:
+            try:
+                check = gather_check(result_fn, from_peer)
+            except Exception as e:   # noqa: BLE001 -- (every rank has left the collectives of gather_check by now or none has)
+                check = f"check failed: {type(e).__name__}: {e}"[:200]
+        else:
+            check = None
+        if failed is not None:
+            failed_modes[name] = failed
+            notes[name] = f"failed: {failed}"
+            if name == "p2p copy engines" and "rccl gather" not in modes:     # (agreed on every rank: `failed` is all-gathered)
+                modes["rccl gather"] = rccl_mode()
+                queue.append(("rccl gather", modes["rccl gather"]))
+            continue
+        results[name] = {"elapsed": elapsed, "kern_ms": kms, "reserve": reserve, "gather_check": check}
+        if name == "p2p copy engines" and rank == 0:
+            # the ring's ready counters after the drain: the last two steps of every rank are marked as landed
+            try:
+                last = peer.steps_done - 1
+                cnt = pg.ready_counters()
+                results[name]["ready_counters_ok"] = bool((cnt[last % pg.n_slots] == last + 1).all() and
+                                                          (pg.n_slots < 2 or last < 1 or (cnt[(last - 1) % pg.n_slots] == last).all()))
+            except Exception as e:   # noqa: BLE001
+                results[name]["ready_counters_ok"] = f"not read: {e}"[:120]
+    if not results:
+        raise SystemExit(f"every gather mode failed: {failed_modes}")
+    # `value` is the first mode's that ran (--gather p2p | rccl | both) or, with --gather auto, the faster one's: nobody has
+    # seen either mode cross two GPUs before the driver's run, so the default times both (K steps each) and says so
     primary = next(iter(results))
+    if a.gather == "auto" and len(results) > 1:
+        primary = min(results, key=lambda n: results[n]["elapsed"])       # (`elapsed` is the MAX over ranks: same on every rank)
     elapsed, kern_ms = results[primary]["elapsed"], results[primary]["kern_ms"]
     assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"
 
@@ -556,11 +619,18 @@ def main():
                               "value_kernel_only": round(pix_per_step / (kern_only * 1e-3) / 1e6, 2),
                               "gather_modes": {n: {"ms_per_step": round(r["elapsed"] / a.steps * 1e3, 4),
                                                    "value": round(pix_per_step * a.steps / r["elapsed"] / 1e6, 2),
-                                                   "cus_left_to_rccl": r["reserve"], "gather_check": r["gather_check"]}
-                                               for n, r in results.items()}}
+                                                   "cus_left_to_rccl": r["reserve"], "gather_check": r["gather_check"],
+                                                   **({"ready_counters_ok": r["ready_counters_ok"]} if "ready_counters_ok" in r else {})}
+                                               for n, r in results.items()},
+                              # what this run could not use, and why (p2p: the receive ring could not be mapped by every rank;
+                              # cu_masked_stream: the RCCL gather then ran beside a kernel on all CUs; a mode that failed mid-run)
+                              "unavailable": notes}
 
         if not a.no_cfg5:
-            c5n = leg_cfg5_all_ranks(5, 2)       # every rank takes part
+            try:
+                c5n = leg_cfg5_all_ranks(5, 2)       # every rank takes part
+            except Exception as e:   # noqa: BLE001 -- the headline is measured; it must still be printed
+                c5n = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:400]}
             out["cfg5_all_ranks"] = c5n
 
     key = f"F{F}_T{T}_D{D}_C{C}_{a.topology}"

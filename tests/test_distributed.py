@@ -1,5 +1,6 @@
 """N>1 path on CPU: 2 gloo ranks, host-memory test double, shards gathered on rank 0 == oracle."""
 import importlib
+import time
 import os
 import socket
 import sys
@@ -113,6 +114,7 @@ def _p2p_worker(rank, world, port, tmpdir, multi_device=False):
         # a rank that cannot map the buffer turns the mode off on EVERY rank (callers then use the RCCL gather)
         broken = dmod.PeerCopyGather(world, rank, nbytes, _fail_open_on_rank=1)
         assert not broken.ok and broken.base is None
+        assert broken.errors and "hipIpcOpenMemHandle" in broken.errors[1]
         gather = dmod.PeerCopyGather(world, rank, nbytes)
         assert gather.ok, "HIP IPC between two processes on one GPU should work"
         pe = dmod.PeerCopyForestEvaluator(ev, forest, frames, (h, w), gather, labels_reduce=r, scale_factor=0.5)
@@ -123,17 +125,49 @@ def _p2p_worker(rank, world, port, tmpdir, multi_device=False):
         pe.drain()
         torch.cuda.synchronize()
         dist.barrier()
+        wants = {}
+
+        def want_for(g, first):
+            if (g, first) not in wants:
+                fr = rdf.synth.mixed_batch(frames, first_idx=first, h=h, w=w)
+                want = np.full((frames, h // r, w // r), 65535, np.uint16)
+                rdf_oracle.eval_forest(fr, forest_np, want, r, scale_factor=0.5)
+                wants[(g, first)] = want
+            return wants[(g, first)]
         if rank == 0:
             got = pe.result().cpu().numpy().view(np.uint16)
             assert got.shape == (world * frames, h // r, w // r)
             for g in range(world):
-                fr = rdf.synth.mixed_batch(frames, first_idx=g * frames, h=h, w=w)
-                want = np.full((frames, h // r, w // r), 65535, np.uint16)
-                rdf_oracle.eval_forest(fr, forest_np, want, r, scale_factor=0.5)
-                assert np.array_equal(got[g * frames:(g + 1) * frames], want), f"shard {g}"
-            open(os.path.join(tmpdir, "ok"), "w").write("ok")
+                assert np.array_equal(got[g * frames:(g + 1) * frames], want_for(g, g * frames)), f"shard {g}"
+            cnt = gather.ready_counters()
+            assert (cnt[4 % 2] == 5).all() and (cnt[3 % 2] == 4).all()        # steps 4 and 3 are marked as landed
         else:
             assert pe.result() is None
+        dist.barrier()
+
+        # ---- the ring as an API: a consumer on rank 0 that is slower than the producers.  Three different batches in turn,
+        # so that a slot overwritten too early (step s + 2 lands in the slot of step s) would show; the producers wait for
+        # the consumer's release before they reuse a slot (flow control) ----
+        gather2 = dmod.PeerCopyGather(world, rank, nbytes, n_slots=2)
+        assert gather2.ok
+        pe2 = dmod.PeerCopyForestEvaluator(ev, forest, frames, (h, w), gather2, labels_reduce=r, scale_factor=0.5, flow_control=True)
+        batches = [rdf.to_device(rdf.synth.mixed_batch(frames, first_idx=1000 * b + rank * frames, h=h, w=w)) for b in range(3)]
+        n_steps = 7
+        for s_no in range(n_steps):
+            pe2.step(batches[s_no % 3], ring, prefill=65535)
+            if rank == 0:
+                time.sleep(0.03)                                   # the consumer dawdles: the producers run ahead and must wait
+                assert gather2.wait_ready(s_no, timeout_s=20.0), s_no
+                got = gather2.slot_array(s_no).cpu().numpy().view(np.uint16).reshape(world * frames, h // r, w // r)
+                for g in range(world):
+                    assert np.array_equal(got[g * frames:(g + 1) * frames], want_for(g, 1000 * (s_no % 3) + g * frames)), (s_no, g)
+                gather2.release(s_no)
+        pe2.drain()
+        torch.cuda.synchronize()
+        if rank == 0:
+            open(os.path.join(tmpdir, "ok"), "w").write("ok")
+        dist.barrier()
+        gather2.close()
         dist.barrier()          # rank 0 is done reading before anyone unmaps
         gather.close()
     finally:
