@@ -467,10 +467,16 @@ class DecisionTreeTrainer:
         self.active_nodes_cu.fill(np.int32(0))          # one node to start, index 0
         self.next_num_active_nodes_cu.fill(np.int32(1))
 
+        self.level_seconds = []      # (filled when self.time_levels is set: one synchronisation per level)
+        time_levels = bool(getattr(self, "time_levels", False))
         for current_level in range(D):
             num_active_nodes = self.get_next_num_active_nodes()
             if num_active_nodes == 0:
                 break
+            if time_levels:
+                import time
+                self._rt.synchronize()
+                t_level = time.perf_counter()
             self.best_gain_seen_per_node.fill(np.float32(-1.))
 
             for _ in range(self.NUM_PROPOSAL_BLOCKS):
@@ -511,6 +517,9 @@ class DecisionTreeTrainer:
             chk(lib.rdf_train_next_active(current_level, D, C, device_ptr(tree.tree_out_cu), self.active_nodes_cu.ptr,
                                           num_active_nodes, self.next_active_nodes_cu.ptr,
                                           self.next_num_active_nodes_cu.ptr, st()), "rdf_train_next_active")
+            if time_levels:
+                self._rt.synchronize()
+                self.level_seconds.append((current_level, num_active_nodes, time.perf_counter() - t_level))
             if current_level == D - 1:
                 break
             self.node_counts_cu.copy_from(self.next_node_counts_cu)

@@ -186,10 +186,19 @@ def train(rdf, images=64, depth=12, proposals=256, blocks=1, noisy_labels=False,
     t = tree.tree_out_cu.get()
     levels = int(np.ceil(np.log2(np.nonzero(np.abs(t).sum(1) > 0)[0].max() + 2)))
     evals = n_lab * proposals * blocks * levels     # upper bound: pixels retire as their nodes become leaves
+    per_level = None
+    if os.environ.get("RDF_TRAIN_LEVELS"):       # where the time goes, level by level (one synchronisation per level)
+        trainer.time_levels = True
+        np.random.seed(1)
+        trainer.train(ds, tree)
+        per_level = [{"level": l, "active_nodes": n, "ms": round(t * 1e3, 2)} for l, n, t in trainer.level_seconds]
+        trainer.time_levels = False
     out = {"images": images, "frame": [h, w], "labelled_pixels": n_lab, "classes": C, "max_depth": depth,
            "levels_trained": levels, "proposals_per_level": proposals * blocks, "seconds": round(dt, 4),
            "seconds_of_3_runs": [round(x, 4) for x in times],
            "G_pixel_proposals_per_s_upper_bound": round(evals / dt / 1e9, 2)}
+    if per_level is not None:
+        out["per_level"] = per_level
     if check:
         D, blk, P, sub = 6, 2, 16, 3
         ds2 = _ArrayDataset(frames[:sub], labels[:sub], C, per_block=3)
