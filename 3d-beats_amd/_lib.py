@@ -51,6 +51,13 @@ SIGNATURES = {
     "rdf_train_histogram_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "rdf_train_histogram_left_ws": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
                                              _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_train_sort_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "rdf_train_bits_row_bytes": (_c_size_t, [_c_int]),
+    "rdf_train_sort_pixels": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_train_bits_workspace_bytes": (_c_size_t, [_c_int]),
+    "rdf_train_decision_bits": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "rdf_train_count_rows": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                                      _c_void_p]),
     "rdf_train_right_counts": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                         _c_void_p]),
     "rdf_train_pick_best": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -1,6 +1,7 @@
 // rdf_device.hpp -- device helpers shared by the forest-evaluation and the training kernels:
-// the reference's __float2int_rd, wrapping coordinate adds, the verified shared-reciprocal divide and the
-// two-source depth probe (staged LDS tile / global memory).
+// the reference's __float2int_rd, wrapping coordinate adds, the verified shared-reciprocal divide, the
+// two-source depth probe (staged LDS tile / global memory) in its round-1 form (ProbeCtx) and in round 3's (TileCtx: tile at
+// LDS address 0, x doubled), the rounding-mode switches of the one-fma divide-and-floor.
 #ifndef RDF_DEVICE_HPP
 #define RDF_DEVICE_HPP
 
@@ -94,6 +95,73 @@ __device__ __forceinline__ int probe_value(const Probe &p)
 {
     const uint32_t g = p.glb_v, l = p.lds_v;
     return (int)(p.from_global ? g : l);
+}
+
+// ---- round 3: divide, floor and add in one fma (rdf_hip.hip, NodeRec16; tools/verify_magic.hip) ----
+constexpr float kNumScale = 512.0f;            // a decoded numerator is 512 * (x + e), 1/4 <= e <= 3/4
+constexpr float kMagic = 12582912.0f;          // 1.5 * 2^23: an fp32 in [2^23, 2^24) counts in units of one
+constexpr uint32_t kMagicBits = 0x4B400000u;   // its bit pattern
+
+// The wave's fp32 rounding mode (MODE.FP_ROUND bits 1:0: 0 = to nearest even, 2 = toward minus infinity).  The level
+// loop's divide-and-floor is one fma in round-down mode (NodeRec16); everything else -- the reciprocal's refinement,
+// the IEEE divides of kFlagExact nodes, the sums of leaf PDFs -- needs round-to-nearest.  The operand ties a switch to
+// the arithmetic around it: what produced `dep` runs before the switch, what uses it afterwards runs after.
+template <typename T>
+__device__ __forceinline__ void set_round_down(T &dep)
+{
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\ts_nop 0" : "+v"(dep));
+}
+template <typename T>
+__device__ __forceinline__ void set_round_nearest(T &dep)
+{
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 0" : "+v"(dep));
+}
+template <typename T>
+__device__ __forceinline__ void pin(T &v)   // v is computed before this point and used only after it
+{
+    asm volatile("" : "+v"(v));
+}
+
+// A depth probe is answered by the staged LDS tile when it falls inside it (cells outside the image hold 65535 there),
+// else by global memory with the per-axis bounds check of cu_utils.hpp:79-86; a probe outside the image is 65535.
+// Coordinates are RELATIVE TO THE STAGED TILE, x doubled (a byte offset): cx2 = 2 (x - tx0), cy = y - ty0.  The loads
+// are only ISSUED here; their values are consumed after all probes of the level have been issued, so every probe of a
+// level is in flight together and nothing waits inside a divergent branch.  A lane outside the tile reads LDS at an
+// address that means nothing (inside the allocation: some cell; beyond it: the hardware returns 0) and discards it.
+// `img_b` is the wave-uniform base of the current image (a scalar register pair), so a far probe's address is one 32-bit
+// byte offset (a call addresses < 2^31 pixels); multiplies are 24-bit (full rate; every factor is < 2^24 when used).
+struct TileCtx {
+    const char *img_b;
+    uint32_t tw2, th, twp2;  // staged tile: 2 x width, height, row pitch in bytes (0, 0, 0: no staged tile)
+    uint32_t W2, H;          // image: 2 x width, height
+    uint32_t tx0_2, ty0;     // image position of the tile's first cell (x doubled), two's complement
+};
+
+struct TileProbe {
+    uint32_t lds_v, glb_v;
+    bool in_tile;
+};
+
+__device__ __forceinline__ TileProbe tprobe_issue(const TileCtx &c, uint32_t cx2, uint32_t cy)
+{
+    TileProbe p;
+    p.in_tile = cx2 < c.tw2 && cy < c.th;
+    // the tile starts at LDS address 0 (the kernel has no static LDS; the launcher checks): byte offset = address
+    p.lds_v = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)(__umul24(cy, c.twp2) + cx2);
+    asm("" : "=v"(p.glb_v));   // only read where in_tile is false
+    if (!p.in_tile) {
+        const uint32_t x2 = cx2 + c.tx0_2, y = cy + c.ty0;
+        p.glb_v = kNoPixel;
+        if (x2 < c.W2 && y < c.H)   // only far lanes touch global memory; the value is consumed after the branch
+            p.glb_v = *reinterpret_cast<const uint16_t *>(c.img_b + (__umul24(y, c.W2) + x2));
+    }
+    return p;
+}
+
+__device__ __forceinline__ int tprobe_value(const TileProbe &p)
+{
+    const uint32_t g = p.glb_v, l = p.lds_v;
+    return (int)(p.in_tile ? l : g);
 }
 
 } // namespace

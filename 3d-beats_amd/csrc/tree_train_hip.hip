@@ -464,6 +464,319 @@ __global__ __launch_bounds__(256) void k_train_update_pixels(const uint16_t *dep
     nodes[i] = status != -1 ? -1 : parent * 2 + (left ? 0 : 1);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: counting without per-wave atomics.  The deep levels were bound by scattered global atomics -- a wave's 64
+// pixels sit in up to 64 different (node, class) groups there, and every group costs an atomic per four proposals.
+// Now, once per level, the live pixels are given ROW NUMBERS in (node, class) order (k_train_sort_*: a counting sort by
+// the live group sizes); per proposal block every live pixel writes its P left/right decisions as one row of bits
+// (k_train_bits: the same probes as before, no ballots, no atomics), and k_train_count_rows walks the rows in order with
+// a proposal slice per lane, adding a group's bits up in registers and touching the count array once per group (or once
+// per chunk of rows for the huge groups of the upper levels).  Integer sums: the same counts whatever the row order.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSortIters = 4;     // distinct keys a wave aggregates before its remaining lanes use an atomic each
+
+struct SortArgs {
+    const uint16_t *labels;
+    const int32_t *nodes;
+    size_t n_px;
+    int C;
+    int slot_shift;        // every key has 2^slot_shift counters, a wave uses the one of its number: the upper levels have a
+                           // handful of keys and a million waves, and atomics on ONE line run at ~90 per microsecond
+    uint32_t *sizes, *offsets, *cursor, *n_rows;   // [n_keys << slot_shift] each, + 1
+    int32_t *pos, *rowkey;
+};
+
+// pass 1 (POSITIONS = false): sizes[key] += 1 for every live pixel; pass 2 (true): pos[pixel] = offsets[key] + its rank,
+// rowkey[pos] = key.  Lanes of a wave that share a key go through ONE atomic (the first kSortIters keys of a wave; at
+// the upper levels a wave holds one or two keys and a million pixels would otherwise queue on four counters).
+template <bool POSITIONS>
+__global__ __launch_bounds__(256) void k_train_sort(const SortArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t slot = ((blockIdx.x * 256u + threadIdx.x) >> 6) & ((1u << a.slot_shift) - 1u);
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) - lane; i0 < a.n_px; i0 += (size_t)gridDim.x * 256) {
+        const size_t i = i0 + lane;
+        int key = -1;
+        if (i < a.n_px) {
+            const int node = a.nodes[i];
+            if (node >= 0) {
+                const uint32_t label = a.labels[i];
+                if (label < (uint32_t)a.C) key = node * a.C + (int)label;
+            }
+        }
+        u64 todo = __ballot(key >= 0);
+        if (!todo) {                                   // (most of a frame is unlabelled background)
+            if (POSITIONS && i < a.n_px) a.pos[i] = -1;
+            continue;
+        }
+        int my_pos = -1;
+        bool mine_done = key < 0;
+        for (int it = 0; it < kSortIters && todo; ++it) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int k0 = __builtin_amdgcn_readfirstlane(__shfl(key, src));
+            const u64 m = __ballot(key == k0);
+            const unsigned n = (unsigned)__popcll(m);
+            unsigned base = 0;
+            const size_t c0 = ((size_t)k0 << a.slot_shift) + slot;
+            if (lane == src) base = POSITIONS ? atomicAdd(a.cursor + c0, n) : atomicAdd(a.sizes + c0, n);
+            if (POSITIONS) {
+                base = (unsigned)__shfl((int)base, src);
+                if (key == k0) my_pos = (int)(a.offsets[c0] + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull)));
+            }
+            if (key == k0) mine_done = true;
+            todo &= ~m;
+        }
+        if (!mine_done) {                              // deep levels: every pixel its own group
+            const size_t c = ((size_t)key << a.slot_shift) + slot;
+            if (POSITIONS) my_pos = (int)(a.offsets[c] + atomicAdd(a.cursor + c, 1u));
+            else atomicAdd(a.sizes + c, 1u);
+        }
+        if (POSITIONS && i < a.n_px) {
+            a.pos[i] = my_pos;
+            if (my_pos >= 0) a.rowkey[my_pos] = key;
+        }
+    }
+}
+
+// exclusive scan of sizes[n_keys] -> offsets, total -> *n_rows.  One workgroup: thread t takes a contiguous run.
+__global__ __launch_bounds__(1024) void k_train_sort_scan(const uint32_t *sizes, uint32_t *offsets, uint32_t *n_rows, int n_keys)
+{
+    __shared__ uint32_t s_sum[1024];
+    const int t = threadIdx.x;
+    const int per = (n_keys + 1023) / 1024;
+    const int b = min(t * per, n_keys), e = min(b + per, n_keys);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += sizes[i];
+    s_sum[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan
+        const uint32_t v = t >= o ? s_sum[t - o] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[t] - sum;
+    for (int i = b; i < e; ++i) {
+        offsets[i] = run;
+        run += sizes[i];
+    }
+    if (t == 1023) *n_rows = s_sum[1023];
+}
+
+struct BitsArgs {
+    const uint16_t *depth;
+    const int32_t *pos;    // row of every pixel, -1 = not live
+    const float *props;    // [P][5] as drawn (the IEEE path), then [P][5] prepared (k_train_prepare_props), then the flag
+    uint32_t *bits;        // [rows][words]
+    uint32_t n_tiles, tiles_x, tiles_y;
+    int W, H, P, words;    // words = 32-bit words per row (P padded to a power of two >= 64, / 32)
+};
+
+// Proposals in the form the one-fma divide-and-floor wants (rdf_hip.hip, NodeRec16): numerator n = 512 * (floor(u) + 1/2),
+// exactly representable for |u| < 2^21; flag = 1.0f when every numerator of the block is in that range (anything
+// make_random_features draws is), else the block takes the IEEE divide.  floor(IEEE u / d) = floor(floor(u) / d) for those
+// u (tools/verify_intoffset.hip), and floor(x / d) is what the fma gives (tools/verify_magic.hip: payload byte 0).
+__global__ __launch_bounds__(256) void k_train_prepare_props(const float *props, float *out, int P)
+{
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_ok = 1;
+    __syncthreads();
+    bool ok = true;
+    for (int i = threadIdx.x; i < P * 5; i += 256) {
+        const float v = props[i];
+        if (i % 5 == 4) { out[i] = v; continue; }
+        const uint32_t b = __float_as_uint(v);
+        const bool fine = (b << 1) == 0u || (((b >> 23) & 0xFFu) - 40u) <= 107u;      // +-0 or 2^-87 <= |v| < 2^21
+        ok = ok && fine;
+        out[i] = fine ? (float)((int)__builtin_floorf(v) * 512 + 256) : 0.0f;
+    }
+    if (!ok) s_ok = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) out[P * 5] = s_ok ? 1.0f : 0.0f;
+}
+
+// One row of P bits per live pixel: bit j = the pixel goes LEFT under proposal j (tree_train.cu:57-58).  Same tiles and
+// staging as k_train_histogram; the probes are the forest kernel's (tile at LDS address 0, x doubled, one fma in
+// round-down mode per coordinate: the kernel has no static LDS).  A lane collects its own decisions 32 at a time, the
+// workgroup's rows meet in LDS and leave as whole 128-byte lines.
+__global__ __launch_bounds__(256) void k_train_bits(const BitsArgs a)
+{
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    uint16_t *s_tile = reinterpret_cast<uint16_t *>(s_dyn);                                      // at LDS address 0 (TileCtx)
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_dyn + kTH * kTW * 2);                      // [256][words + 1]
+    uint32_t *s_mail = s_bits + 256 * (a.words + 1);                                             // next tile, "any live" x 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per_img = (uint32_t)a.W * (uint32_t)a.H;
+    const int pitch = a.words + 1;             // (odd: lanes that write the same word of their rows hit different banks)
+    const float *nprops = a.props + (size_t)a.P * 5;
+    const bool all_fast = nprops[(size_t)a.P * 5] != 0.0f;          // (wave-uniform, scalar load)
+    if (tid == 0) s_mail[1] = s_mail[2] = 0u;
+
+    for (uint32_t it = 0;; ++it) {
+        if (tid == 0) s_mail[0] = atomicAdd(&g_train_queue[0], 1u);
+        __syncthreads();
+        const uint32_t tile = s_mail[0];
+        if (tile >= a.n_tiles) break;
+        const uint32_t per = a.tiles_x * a.tiles_y;
+        const uint32_t img = tile / per, rem = tile - img * per;
+        const uint32_t ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        const int x = (int)(tx * kCols) + wave * kBW + (lane % kBW), y = (int)(ty * kRows) + lane / kBW;
+        const int tx0 = (int)(tx * kCols) - kHalo, ty0 = (int)(ty * kRows) - kHalo;
+        const size_t img_off = (size_t)img * per_img;
+
+        int row = -1;
+        if (x < a.W && y < a.H) row = a.pos[img_off + (size_t)y * a.W + x];
+        const bool live = row >= 0;
+        // workgroup-wide OR through two alternating words (no static LDS: see the forest kernel's empty-tile test)
+        if (__any(live) && lane == 0) s_mail[1u + (it & 1u)] = 1u;
+        __syncthreads();                                               // (also: the previous tile's readers are done, s_mail[0] is read)
+        const uint32_t any_live = s_mail[1u + (it & 1u)];
+        if (tid == 0) s_mail[1u + ((it + 1u) & 1u)] = 0u;
+        if (any_live == 0u) continue;
+
+        for (int r = wave; r < kTH; r += 4) {
+            const int gy = ty0 + r;
+            const bool row_in = (uint32_t)gy < (uint32_t)a.H;
+            for (int col = lane; col < kTW; col += 64) {
+                const int gx = tx0 + col;
+                uint32_t v = kNoPixel;
+                if (row_in && (uint32_t)gx < (uint32_t)a.W) v = a.depth[img_off + (size_t)gy * a.W + gx];
+                s_tile[r * kTW + col] = (uint16_t)v;
+            }
+        }
+        __syncthreads();
+
+        if (!__any(live)) continue;   // wave-uniform; no barrier below this point in the iteration
+        const int xl = x - tx0, yl = y - ty0;
+        const uint32_t d = live ? s_tile[yl * kTW + xl] : 1u;
+        const float df = (float)(d == 0u ? 1u : d);
+        const float r0 = __builtin_amdgcn_rcpf(df);
+        const float rcp = __builtin_fmaf(__builtin_fmaf(-df, r0, 1.0f), r0, r0);
+        float rcp_s = rcp * (1.0f / kNumScale);
+        const bool zero_depth = d == 0u;              // compute_feature returns 0.f (decision_tree_common.hpp:12)
+        const TileCtx pc = {reinterpret_cast<const char *>(a.depth) + img_off * 2, (uint32_t)kTW * 2u, (uint32_t)kTH,
+                            (uint32_t)kTW * 2u, (uint32_t)a.W * 2u, (uint32_t)a.H, (uint32_t)tx0 * 2u, (uint32_t)ty0};
+        uint32_t kx2 = ((uint32_t)xl - kMagicBits) * 2u;
+        const uint32_t ky = (uint32_t)yl - kMagicBits;
+        pin(kx2);
+        if (all_fast) set_round_down(rcp_s);          // (the loop below has no other rounding arithmetic)
+
+        uint32_t word = 0u;
+        for (int jb = 0; jb < a.P; jb += kBatch) {
+            TileProbe pu[kBatch], pv[kBatch];
+            float thr[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int j = min(jb + k, a.P - 1);               // tail: repeat the last proposal, result unused
+                uint32_t cux, cuy, cvx, cvy;
+                if (all_fast) {                                   // wave-uniform
+                    const float *p = nprops + (size_t)j * 5;
+                    thr[k] = p[4];
+                    const f2 nu = {p[0], p[1]}, nv = {p[2], p[3]}, r2 = {rcp_s, rcp_s}, m2 = {kMagic, kMagic};
+                    const f2 tu = __builtin_elementwise_fma(nu, r2, m2), tv = __builtin_elementwise_fma(nv, r2, m2);
+                    cux = (__float_as_uint(tu.x) << 1) + kx2; cuy = __float_as_uint(tu.y) + ky;
+                    cvx = (__float_as_uint(tv.x) << 1) + kx2; cvy = __float_as_uint(tv.y) + ky;
+                } else {
+                    const float *p = a.props + (size_t)j * 5;
+                    thr[k] = p[4];
+                    cux = (uint32_t)min(max(add_wrap(xl, floor_i32(p[0] / df)), -(1 << 30)), (1 << 30) - 1) * 2u;
+                    cuy = (uint32_t)add_wrap(yl, floor_i32(p[1] / df));
+                    cvx = (uint32_t)min(max(add_wrap(xl, floor_i32(p[2] / df)), -(1 << 30)), (1 << 30) - 1) * 2u;
+                    cvy = (uint32_t)add_wrap(yl, floor_i32(p[3] / df));
+                }
+                pu[k] = tprobe_issue(pc, cux, cuy);
+                pv[k] = tprobe_issue(pc, cvx, cvy);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const float f = zero_depth ? 0.0f : (float)(tprobe_value(pu[k]) - tprobe_value(pv[k]));
+                const uint32_t left = (jb + k) < a.P && f < thr[k] ? 1u : 0u;      // tree_train.cu:57-58
+                word |= left << ((jb + k) & 31);
+            }
+            if (((jb + kBatch) & 31) == 0 || jb + kBatch >= a.P) {     // (kBatch divides 32)
+                s_bits[tid * pitch + (jb >> 5)] = word;
+                word = 0u;
+            }
+        }
+        if (all_fast) { pin(word); set_round_nearest(word); }
+        // words of the padding beyond P (rows are padded to a power of two)
+        for (int w = (a.P + 31) >> 5; w < a.words; ++w) s_bits[tid * pitch + w] = 0u;
+        // the wave's rows leave as whole lines (a wave only reads what its own lanes wrote: no barrier)
+        for (int r = 0; r < 64; ++r) {
+            const int dst = __shfl(row, r);
+            if (dst < 0) continue;                                     // wave-uniform
+            for (int w = lane; w < a.words; w += 64)
+                a.bits[(size_t)dst * a.words + w] = s_bits[(wave * 64 + r) * pitch + w];
+        }
+    }
+    if (tid == 0) {   // every workgroup has made its final, failing pull before it gets here
+        const unsigned int done = atomicAdd(&g_train_queue[1], 1u);
+        if (done == gridDim.x - 1u) {
+            atomicExch(&g_train_queue[0], 0u);
+            atomicExch(&g_train_queue[1], 0u);
+        }
+    }
+}
+
+struct CountArgs {
+    const uint32_t *bits;
+    const int32_t *rowkey;
+    const uint32_t *n_rows;
+    u64 *counts;          // [P][NB][C]
+    int P, words, q;      // q = bits of a row per lane = 32 * words / 64 (a power of two, 1..32)
+    int C, NB, node_start, node_end;
+};
+
+// Rows in (node, class) order; a wave takes a contiguous chunk of them.  Lane l owns proposals l*q .. l*q + q - 1: it adds
+// the bits of a group's rows up in q registers and flushes them into counts[j][left child's bin] when the group (or the
+// chunk) ends -- one atomic per (group, proposal) where the histogram kernel spent one per (wave, group, four proposals).
+template <int Q>
+__global__ __launch_bounds__(256) void k_train_count_rows(const CountArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_rows = *a.n_rows;
+    const uint32_t n_waves = gridDim.x * 4u, wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t chunk = (n_rows + n_waves - 1u) / n_waves;
+    chunk = (chunk + 63u) & ~63u;
+    const uint32_t r0 = wave_id * chunk, r1 = min(r0 + chunk, n_rows);
+    if (r0 >= r1) return;
+    const int word_of_lane = (lane * Q) >> 5, shift = (lane * Q) & 31;
+    uint32_t cnt[Q];
+#pragma unroll
+    for (int m = 0; m < Q; ++m) cnt[m] = 0u;
+    int cur_key = -1;
+    auto flush = [&](int key) {
+        if (key < 0) return;
+        const int node = key / a.C, label = key - node * a.C;
+        if (node * 2 < a.node_start || node * 2 + 1 >= a.node_end) return;     // (children outside this node block)
+        const size_t bin = (size_t)(node * 2 - a.node_start) * a.C + label;
+#pragma unroll
+        for (int m = 0; m < Q; ++m) {
+            const int j = lane * Q + m;
+            if (cnt[m] && j < a.P) atomicAdd(a.counts + (size_t)j * a.NB * a.C + bin, (u64)cnt[m]);
+        }
+    };
+    for (uint32_t rb = r0; rb < r1; rb += 64u) {
+        const uint32_t r_mine = rb + (uint32_t)lane;
+        const int key_mine = r_mine < r1 ? a.rowkey[r_mine] : -1;
+        const int n_here = (int)min(64u, r1 - rb);
+        for (int i = 0; i < n_here; ++i) {
+            const int key = __builtin_amdgcn_readfirstlane(__shfl(key_mine, i));
+            if (key != cur_key) {
+                flush(cur_key);
+#pragma unroll
+                for (int m = 0; m < Q; ++m) cnt[m] = 0u;
+                cur_key = key;
+            }
+            const uint32_t w = a.bits[(size_t)(rb + (uint32_t)i) * a.words + word_of_lane] >> shift;
+#pragma unroll
+            for (int m = 0; m < Q; ++m) cnt[m] += (w >> m) & 1u;
+        }
+    }
+    flush(cur_key);
+}
+
 } // namespace
 
 extern "C" {
@@ -575,6 +888,140 @@ int rdf_train_histogram_left_ws(const uint16_t *depth, const uint16_t *labels, c
     if (!workspace) return RDF_ERR_NULL_PTR;
     return train_histogram(depth, labels, nodes_by_pixel, n_img, dim_x, dim_y, proposals, n_proposals, n_classes,
                            node_start, node_end, nodes_per_block, counts, 1, workspace, parent_counts, stream);
+}
+
+
+constexpr int kSortCounters = 16384;     // counters a level with few keys spreads them over (2^slot_shift per key)
+
+static int sort_slot_shift(long long n_keys)
+{
+    int sh = 0;
+    while (sh < 8 && (n_keys << (sh + 1)) <= kSortCounters) ++sh;
+    return sh;
+}
+
+size_t rdf_train_sort_workspace_bytes(int n_nodes, int n_classes)
+{
+    if (n_nodes < 0 || n_classes < 0) return 0;
+    size_t n = (size_t)n_nodes * (size_t)n_classes;
+    if (n < (size_t)kSortCounters) n = kSortCounters;
+    return (n * 3u + 4u) * sizeof(uint32_t);
+}
+
+static int bits_words(int n_proposals)     // 32-bit words of a row: P padded to a power of two >= 64
+{
+    int p = 64;
+    while (p < n_proposals) p <<= 1;
+    return p / 32;
+}
+
+size_t rdf_train_bits_row_bytes(int n_proposals)
+{
+    if (n_proposals < 1 || n_proposals > 1024) return 0;
+    return (size_t)bits_words(n_proposals) * 4u;
+}
+
+size_t rdf_train_bits_workspace_bytes(int n_proposals)
+{
+    if (n_proposals < 0) return 0;
+    return ((size_t)n_proposals * 10u + 4u) * sizeof(float);
+}
+
+int rdf_train_sort_pixels(const uint16_t *labels, const int32_t *nodes_by_pixel, size_t n_px, int n_classes, int n_nodes,
+                          int32_t *pos, int32_t *rowkey, void *workspace, void *stream)
+{
+    if (n_classes < 1 || n_classes > kMaxClasses || n_nodes < 1 || (long long)n_nodes * n_classes >= (1ll << 30)) return RDF_ERR_BAD_ARG;
+    if (n_px >= ((size_t)1 << 31)) return RDF_ERR_TOO_LARGE;
+    if (!workspace) return RDF_ERR_NULL_PTR;
+    const int shift = sort_slot_shift((long long)n_nodes * n_classes);
+    const int n_keys = (n_nodes * n_classes) << shift;        // counters
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(workspace, 0, ((size_t)n_keys * 3u + 4u) * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (n_px == 0) return RDF_OK;
+    if (!labels || !nodes_by_pixel || !pos || !rowkey) return RDF_ERR_NULL_PTR;
+    SortArgs a;
+    a.labels = labels; a.nodes = nodes_by_pixel; a.n_px = n_px; a.C = n_classes; a.slot_shift = shift;
+    a.sizes = reinterpret_cast<uint32_t *>(workspace);
+    a.offsets = a.sizes + n_keys;
+    a.cursor = a.offsets + n_keys;
+    a.n_rows = a.cursor + n_keys;
+    a.pos = pos; a.rowkey = rowkey;
+    size_t blocks = (n_px + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_train_sort<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_train_sort_scan, dim3(1), dim3(1024), 0, st, a.sizes, a.offsets, a.n_rows, n_keys);
+    hipLaunchKernelGGL(k_train_sort<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int rdf_train_decision_bits(const uint16_t *depth, const int32_t *pos, int n_img, int dim_x, int dim_y,
+                            const float *proposals, int n_proposals, void *bits, void *workspace, void *stream)
+{
+    if (n_img < 0 || dim_x < 0 || dim_y < 0 || n_proposals < 0 || n_proposals > 1024) return RDF_ERR_BAD_ARG;
+    if ((long long)n_img * dim_x * dim_y >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    if (n_img == 0 || dim_x == 0 || dim_y == 0 || n_proposals == 0) return RDF_OK;
+    if (!depth || !pos || !proposals || !bits || !workspace) return RDF_ERR_NULL_PTR;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // the proposals as drawn, then in the form the one-fma divide wants, then the "all in range" flag
+    float *props2 = reinterpret_cast<float *>(workspace);
+    hipError_t ec = hipMemcpyAsync(props2, proposals, (size_t)n_proposals * 5 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (ec != hipSuccess) return (int)ec;
+    hipLaunchKernelGGL(k_train_prepare_props, dim3(1), dim3(256), 0, st, proposals, props2 + (size_t)n_proposals * 5, n_proposals);
+    BitsArgs a;
+    a.depth = depth; a.pos = pos; a.props = props2; a.bits = reinterpret_cast<uint32_t *>(bits);
+    a.W = dim_x; a.H = dim_y; a.P = n_proposals; a.words = bits_words(n_proposals);
+    a.tiles_x = (uint32_t)(dim_x + kCols - 1) / kCols;
+    a.tiles_y = (uint32_t)(dim_y + kRows - 1) / kRows;
+    const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
+    if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    a.n_tiles = (uint32_t)n_tiles;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long grid = (long long)cus * 4;
+    if (grid > n_tiles) grid = n_tiles;
+    void *q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_train_queue)) != hipSuccess || !q) return RDF_ERR_NO_DEVICE;
+    const hipError_t eq = hipMemsetAsync(q, 0, sizeof(unsigned int) * 2, st);
+    if (eq != hipSuccess) return (int)eq;
+    static_assert((kTH * kTW * 2) % 16 == 0, "the bit rows start 16-byte aligned behind the tile");
+    hipFuncAttributes fa;      // the probes address the tile as LDS address 0 + offset (TileCtx): no static LDS allowed
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_train_bits)) != hipSuccess || fa.sharedSizeBytes != 0)
+        return RDF_ERR_NO_DEVICE;
+    const int lds = kTH * kTW * 2 + 256 * (a.words + 1) * 4 + 16;
+    hipLaunchKernelGGL(k_train_bits, dim3((unsigned)grid), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+int rdf_train_count_rows(const void *bits, const int32_t *rowkey, const void *sort_workspace, int n_nodes, int n_proposals,
+                         int n_classes, int node_start, int node_end, int nodes_per_block, unsigned long long *counts,
+                         void *stream)
+{
+    if (n_proposals < 0 || n_proposals > 1024 || n_classes < 1 || n_classes > kMaxClasses || n_nodes < 1 || nodes_per_block < 1 ||
+        node_end - node_start > nodes_per_block || node_start < 0)
+        return RDF_ERR_BAD_ARG;
+    if (n_proposals == 0) return RDF_OK;
+    if (!bits || !rowkey || !sort_workspace || !counts) return RDF_ERR_NULL_PTR;
+    CountArgs a;
+    a.bits = reinterpret_cast<const uint32_t *>(bits);
+    a.rowkey = rowkey;
+    a.n_rows = reinterpret_cast<const uint32_t *>(sort_workspace) +
+               ((size_t)(n_nodes * n_classes) << sort_slot_shift((long long)n_nodes * n_classes)) * 3u;
+    a.counts = counts;
+    a.P = n_proposals; a.words = bits_words(n_proposals); a.q = a.words * 32 / 64;
+    a.C = n_classes; a.NB = nodes_per_block; a.node_start = node_start; a.node_end = node_end;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const dim3 grid((unsigned)cus * 8u), block(256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (a.q) {
+    case 1: hipLaunchKernelGGL(k_train_count_rows<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_train_count_rows<2>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_train_count_rows<4>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(k_train_count_rows<8>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(k_train_count_rows<16>, grid, block, 0, st, a); break;
+    }
+    return (int)hipGetLastError();
 }
 
 int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,

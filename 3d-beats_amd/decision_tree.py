@@ -448,6 +448,20 @@ class DecisionTreeTrainer:
             dataset.get_depth_block_cu(b, self.depth_cu[b * ipb:(b + 1) * ipb])
             dataset.get_labels_block_cu(b, self.labels_cu[b * ipb:(b + 1) * ipb])
 
+        # Counting by sorted rows (rdf_train_sort_pixels / _decision_bits / _count_rows): one row of P bits per labelled
+        # pixel, rows in (node, class) order.  Used for proposal blocks of up to 1024 proposals; bigger blocks keep the
+        # histogram kernel with its per-wave atomics.  `use_sorted_rows = False` forces the latter (tests compare the two).
+        row_bytes = int(self._lib.rdf_train_bits_row_bytes(P))
+        self.use_sorted_rows = row_bytes > 0
+        if self.use_sorted_rows:
+            t = self.labels_cu.torch_bytes().view(self._rt.torch.int16)
+            n_labelled = int((t != 0).sum().item())
+            self.pixel_rows_cu = DeviceArray(shape, np.int32)
+            self.row_keys_cu = DeviceArray((max(n_labelled, 1),), np.int32)
+            self.decision_bits_cu = DeviceArray((max(n_labelled, 1) * row_bytes,), np.uint8)
+            self._sort_workspace = DeviceArray((int(self._lib.rdf_train_sort_workspace_bytes(self.MAX_LEAF_NODES, C)),), np.uint8)
+            self._bits_workspace = DeviceArray((int(self._lib.rdf_train_bits_workspace_bytes(P)),), np.uint8)
+
     def train(self, dataset, tree):
         lib, st = self._lib, self._rt.stream
         C = dataset.num_classes()
@@ -478,10 +492,21 @@ class DecisionTreeTrainer:
                 self._rt.synchronize()
                 t_level = time.perf_counter()
             self.best_gain_seen_per_node.fill(np.float32(-1.))
+            sorted_rows = self.use_sorted_rows
+            n_level_nodes = 2 ** current_level
+            if sorted_rows:      # once per level: every live pixel's row in (node, class) order
+                chk(lib.rdf_train_sort_pixels(self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr, self.labels_cu.size, C,
+                                              n_level_nodes, self.pixel_rows_cu.ptr, self.row_keys_cu.ptr,
+                                              self._sort_workspace.ptr, st()), "rdf_train_sort_pixels")
 
             for _ in range(self.NUM_PROPOSAL_BLOCKS):
                 make_random_features(P, self.current_proposals_block_cpu)
                 self.current_proposals_block.set(self.current_proposals_block_cpu)
+                if sorted_rows:  # once per proposal block: the decisions of every live pixel (they do not depend on the node block)
+                    chk(lib.rdf_train_decision_bits(self.depth_cu.ptr, self.pixel_rows_cu.ptr, n_img, dim_x, dim_y,
+                                                    self.current_proposals_block.ptr, P, self.decision_bits_cu.ptr,
+                                                    self._bits_workspace.ptr, st()),
+                        "rdf_train_decision_bits")
 
                 max_active_nodes_next_level = 2 ** (current_level + 1)
                 if max_active_nodes_next_level > self.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK:
@@ -495,12 +520,18 @@ class DecisionTreeTrainer:
                     self.current_next_node_counts_by_feature_cu_block.fill(0)
                     # evaluate_random_features, as two calls: the kernel counts the left children, the right ones
                     # follow from the parents' counts (the whole training set is counted in this one call)
-                    chk(lib.rdf_train_histogram_left_ws(self.depth_cu.ptr, self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr,
-                                                        n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
-                                                        node_block_start, node_block_end, NB,
-                                                        self.current_next_node_counts_by_feature_cu_block.ptr,
-                                                        self._hist_workspace.ptr, self.node_counts_cu.ptr, st()),
-                        "rdf_train_histogram_left_ws")
+                    if sorted_rows:
+                        chk(lib.rdf_train_count_rows(self.decision_bits_cu.ptr, self.row_keys_cu.ptr, self._sort_workspace.ptr,
+                                                     n_level_nodes, P, C, node_block_start, node_block_end, NB,
+                                                     self.current_next_node_counts_by_feature_cu_block.ptr, st()),
+                            "rdf_train_count_rows")
+                    else:
+                        chk(lib.rdf_train_histogram_left_ws(self.depth_cu.ptr, self.labels_cu.ptr, self.nodes_by_pixel_cu.ptr,
+                                                            n_img, dim_x, dim_y, self.current_proposals_block.ptr, P, C,
+                                                            node_block_start, node_block_end, NB,
+                                                            self.current_next_node_counts_by_feature_cu_block.ptr,
+                                                            self._hist_workspace.ptr, self.node_counts_cu.ptr, st()),
+                            "rdf_train_histogram_left_ws")
                     chk(lib.rdf_train_right_counts(num_active_nodes, self.active_nodes_cu.ptr, P, NB, node_block_start,
                                                    node_block_end, C, self.node_counts_cu.ptr,
                                                    self.current_next_node_counts_by_feature_cu_block.ptr, st()),

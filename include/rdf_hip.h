@@ -243,6 +243,28 @@ int rdf_train_histogram_left_ws(const uint16_t *depth, const uint16_t *labels, c
                                 int dim_x, int dim_y, const float *proposals, int n_proposals, int n_classes,
                                 int node_start, int node_end, int nodes_per_block, unsigned long long *counts,
                                 void *workspace, const unsigned long long *parent_counts, void *stream);
+/*
+ * The same left-child counts without an atomic per (wave, group): once per level rdf_train_sort_pixels gives every live
+ * pixel (nodes_by_pixel >= 0, label < n_classes) a row number in (node, class) order (pos[pixel], -1 for the others;
+ * rowkey[row] = node * n_classes + label; the number of rows is kept in the workspace, which the call zeroes itself:
+ * rdf_train_sort_workspace_bytes(n_nodes, n_classes) bytes, n_nodes = nodes of the current level);
+ * per proposal block rdf_train_decision_bits writes one row of bits per live pixel (bit j = the pixel goes left under
+ * proposal j; rdf_train_bits_row_bytes(n_proposals) bytes per row, n_proposals <= 1024, rows for every labelled pixel
+ * must fit) and rdf_train_count_rows adds the rows of each (node, class) group up into
+ * counts[j][left child - node_start][class], exactly what rdf_train_histogram_left leaves there (counts is zeroed by the
+ * caller; rdf_train_right_counts then fills the right children).  The decision bits do not depend on the node block:
+ * one rdf_train_decision_bits serves every rdf_train_count_rows of a proposal block.
+ */
+size_t rdf_train_sort_workspace_bytes(int n_nodes, int n_classes);
+size_t rdf_train_bits_row_bytes(int n_proposals);
+size_t rdf_train_bits_workspace_bytes(int n_proposals);   /* scratch of rdf_train_decision_bits (the proposals, prepared) */
+int rdf_train_sort_pixels(const uint16_t *labels, const int32_t *nodes_by_pixel, size_t n_px, int n_classes, int n_nodes,
+                          int32_t *pos, int32_t *rowkey, void *workspace, void *stream);
+int rdf_train_decision_bits(const uint16_t *depth, const int32_t *pos, int n_img, int dim_x, int dim_y,
+                            const float *proposals, int n_proposals, void *bits, void *workspace, void *stream);
+int rdf_train_count_rows(const void *bits, const int32_t *rowkey, const void *sort_workspace, int n_nodes, int n_proposals,
+                         int n_classes, int node_start, int node_end, int nodes_per_block, unsigned long long *counts,
+                         void *stream);
 int rdf_train_right_counts(int n_active, const int32_t *active_nodes, int n_proposals, int nodes_per_block,
                            int node_start, int node_end, int n_classes, const unsigned long long *parent_counts,
                            unsigned long long *counts, void *stream);

@@ -61,9 +61,12 @@ def test_numpy_trainer_learns_a_separable_problem(rdf, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sorted_rows", [True, False], ids=["sorted_rows", "wave_atomics"])
 @pytest.mark.parametrize("cfg", [(6, 2, 16, 1 << 17), (5, 1, 40, 1 << 17), (7, 3, 8, 8)],
                          ids=["D6_2x16", "D5_1x40", "D7_3x8_nodeblocks8"])
-def test_device_trainer_matches_restatement_bit_for_bit(cfg, rdf, gpu_runtime):
+def test_device_trainer_matches_restatement_bit_for_bit(cfg, sorted_rows, rdf, gpu_runtime):
+    """Both ways of counting -- rows of decision bits in (node, class) order (the default) and the histogram kernel with
+    its per-wave atomics -- train the restatement's tree, bit for bit."""
     D, blocks, P, max_nodes = cfg
     depth, labels = make_data(rdf, n=6)
     C = 4
@@ -71,6 +74,8 @@ def test_device_trainer_matches_restatement_bit_for_bit(cfg, rdf, gpu_runtime):
     trainer = rdf.DecisionTreeTrainer(3, P)
     trainer.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK = max_nodes
     trainer.allocate(ds, blocks * P, D)
+    assert trainer.use_sorted_rows
+    trainer.use_sorted_rows = sorted_rows
     tree = rdf.DecisionTree(D, C)
     np.random.seed(7)
     trainer.train(ds, tree)
@@ -128,6 +133,68 @@ def test_histogram_variants_agree_when_big_and_small_bins_mix(rdf, gpu_runtime):
         assert np.array_equal(fast.get(), plain.get())
         assert not ws.get().any()
     assert plain.get().sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [37, 64, 200, 1024])
+def test_sorted_row_counts_equal_the_histogram_kernels(P, rdf, gpu_runtime):
+    """rdf_train_sort_pixels + rdf_train_decision_bits + rdf_train_count_rows leave the count array exactly as
+    rdf_train_histogram_left does: on the deepest level of a trained tree (many small groups), in node blocks, with pixels
+    whose label is beyond the class count, and for proposal counts that are no power of two."""
+    import ctypes
+    dt = importlib.import_module("3d-beats_amd.decision_tree")
+    depth, labels = make_data(rdf, n=6)
+    labels = labels.copy()
+    labels[0, :4, :9] = 9                      # labels >= C are ignored by both paths
+    C, D = 4, 7
+    ds = _ArrayDataset(depth, labels, C, per_block=6)
+    trainer = rdf.DecisionTreeTrainer(6, 24)
+    trainer.allocate(ds, 24, D)
+    tree = rdf.DecisionTree(D, C)
+    np.random.seed(31)
+    trainer.train(ds, tree)                    # leaves nodes_by_pixel at level D - 1
+    lib, st = gpu_runtime.lib, gpu_runtime.stream
+    n, h, w = depth.shape
+    level = D - 1
+    n_nodes = 2 ** level
+    nodes_px = trainer.nodes_by_pixel_cu.get()
+    assert len(np.unique(nodes_px[nodes_px >= 0])) > 8
+    props = np.zeros((P, 5), np.float32)
+    np.random.seed(32)
+    dt.make_random_features(P, props)
+    d_props = rdf.to_device(props)
+    row_bytes = int(lib.rdf_train_bits_row_bytes(P))
+    assert row_bytes == {37: 8, 64: 8, 200: 32, 1024: 128}[P]
+    n_lab = int((labels != 0).sum())
+    pos = rdf.DeviceArray(depth.shape, np.int32)
+    rowkey = rdf.DeviceArray((n_lab,), np.int32)
+    bits = rdf.DeviceArray((n_lab * row_bytes,), np.uint8)
+    work = rdf.DeviceArray((int(lib.rdf_train_sort_workspace_bytes(n_nodes, C)),), np.uint8).fill(255)   # (the call zeroes it)
+    assert lib.rdf_train_sort_pixels(trainer.labels_cu.ptr, trainer.nodes_by_pixel_cu.ptr, depth.size, C, n_nodes, pos.ptr,
+                                     rowkey.ptr, work.ptr, st()) == 0
+    # the rows are a permutation of the live pixels, grouped by (node, class) in ascending order
+    lab = labels
+    live = (nodes_px >= 0) & (lab < C)
+    got_pos = pos.get()
+    assert (got_pos[~live] == -1).all()
+    rows = got_pos[live]
+    assert sorted(rows.tolist()) == list(range(int(live.sum())))
+    keys = rowkey.get()[:int(live.sum())]
+    assert (np.diff(keys) >= 0).all()
+    assert np.array_equal(keys[rows], (nodes_px[live] * C + lab[live]).astype(np.int32))
+    bws = rdf.DeviceArray((int(lib.rdf_train_bits_workspace_bytes(P)),), np.uint8)
+    assert lib.rdf_train_decision_bits(trainer.depth_cu.ptr, pos.ptr, n, w, h, d_props.ptr, P, bits.ptr, bws.ptr, st()) == 0
+    for NB in (2 * n_nodes, 16):               # one node block, then blocks of 16 next-level nodes
+        for start in range(0, 2 * n_nodes, NB):
+            end = start + NB
+            want = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
+            assert lib.rdf_train_histogram_left(trainer.depth_cu.ptr, trainer.labels_cu.ptr, trainer.nodes_by_pixel_cu.ptr, n, w, h,
+                                                d_props.ptr, P, C, start, end, NB, want.ptr, st()) == 0
+            got = rdf.DeviceArray((P, NB, C), np.uint64).fill(0)
+            assert lib.rdf_train_count_rows(bits.ptr, rowkey.ptr, work.ptr, n_nodes, P, C, start, end, NB, got.ptr, st()) == 0
+            assert np.array_equal(got.get(), want.get()), (P, NB, start)
+            if NB == 2 * n_nodes:
+                assert want.get().sum() > 0
 
 
 @pytest.mark.gpu
