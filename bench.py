@@ -853,6 +853,7 @@ def main():
             leg("hand_pipeline", lambda: bench_legs.hand_pipeline(rdf))
             leg("mean_shift", lambda: bench_legs.mean_shift(rdf))
             leg("train", lambda: bench_legs.train(rdf))
+            leg("train_256_frames_d16", lambda: bench_legs.train(rdf, images=256, depth=16, proposals=1024, check=False))
 
         # ---- config 5's shard last: it frees the headline's buffers first (2 GiB forest + 2.5 GiB packed tables) ----
         if not a.no_cfg5:

@@ -76,6 +76,7 @@ def test_device_trainer_matches_restatement_bit_for_bit(cfg, sorted_rows, rdf, g
     trainer.allocate(ds, blocks * P, D)
     assert trainer.use_sorted_rows
     trainer.use_sorted_rows = sorted_rows
+    trainer.SORTED_ROWS_FROM_ACTIVE_NODES = 1      # (every level by sorted rows, the root included)
     tree = rdf.DecisionTree(D, C)
     np.random.seed(7)
     trainer.train(ds, tree)
