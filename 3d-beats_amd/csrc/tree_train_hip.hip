@@ -596,21 +596,25 @@ __global__ __launch_bounds__(256) void k_train_prepare_props(const float *props,
     if (threadIdx.x == 0) out[P * 5] = s_ok ? 1.0f : 0.0f;
 }
 
-// One row of P bits per live pixel: bit j = the pixel goes LEFT under proposal j (tree_train.cu:57-58).  Same tiles and
-// staging as k_train_histogram; the probes are the forest kernel's (tile at LDS address 0, x doubled, one fma in
-// round-down mode per coordinate: the kernel has no static LDS).  A lane collects its own decisions 32 at a time, the
-// workgroup's rows meet in LDS and leave as whole 128-byte lines.
+// One row of P bits per live pixel: bit j = the pixel goes LEFT under proposal j (tree_train.cu:57-58).  The histogram
+// kernel's tiles (a wave = an 8 x 8 block, four side by side) with a 32-pixel halo (16 there), and the forest kernel's
+// probes: tile at LDS address 0, x doubled, one fma in round-down mode per coordinate (the kernel has no static LDS).  A lane
+// collects its own decisions 32 at a time and stores them 16 bytes at a time straight into its row: LDS holds the tile only,
+// so occupancy is set by registers (the first version staged the rows in LDS, 38 KB per workgroup, four workgroups per CU:
+// TA 66 % busy, VALU 45 %, nothing at its limit).
+constexpr int kHaloB = 32;      // (24, 40 and 48 measured the same on the 256-frame benchmark: 0.556-0.559 s)
+constexpr int kTWb = kCols + 2 * kHaloB, kTHb = kRows + 2 * kHaloB;
+
 __global__ __launch_bounds__(256) void k_train_bits(const BitsArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint16_t *s_tile = reinterpret_cast<uint16_t *>(s_dyn);                                      // at LDS address 0 (TileCtx)
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_dyn + kTH * kTW * 2);                      // [256][words + 1]
-    uint32_t *s_mail = s_bits + 256 * (a.words + 1);                                             // next tile, "any live" x 2
+    uint32_t *s_mail = reinterpret_cast<uint32_t *>(s_dyn + kTHb * kTWb * 2);                    // next tile, "any live" x 2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t per_img = (uint32_t)a.W * (uint32_t)a.H;
-    const int pitch = a.words + 1;             // (odd: lanes that write the same word of their rows hit different banks)
     const float *nprops = a.props + (size_t)a.P * 5;
     const bool all_fast = nprops[(size_t)a.P * 5] != 0.0f;          // (wave-uniform, scalar load)
+    const int words_used = (a.P + 31) >> 5;
     if (tid == 0) s_mail[1] = s_mail[2] = 0u;
 
     for (uint32_t it = 0;; ++it) {
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(256) void k_train_bits(const BitsArgs a)
         const uint32_t img = tile / per, rem = tile - img * per;
         const uint32_t ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
         const int x = (int)(tx * kCols) + wave * kBW + (lane % kBW), y = (int)(ty * kRows) + lane / kBW;
-        const int tx0 = (int)(tx * kCols) - kHalo, ty0 = (int)(ty * kRows) - kHalo;
+        const int tx0 = (int)(tx * kCols) - kHaloB, ty0 = (int)(ty * kRows) - kHaloB;
         const size_t img_off = (size_t)img * per_img;
 
         int row = -1;
@@ -635,79 +639,91 @@ __global__ __launch_bounds__(256) void k_train_bits(const BitsArgs a)
         if (tid == 0) s_mail[1u + ((it + 1u) & 1u)] = 0u;
         if (any_live == 0u) continue;
 
-        for (int r = wave; r < kTH; r += 4) {
+        for (int r = wave; r < kTHb; r += 4) {
             const int gy = ty0 + r;
             const bool row_in = (uint32_t)gy < (uint32_t)a.H;
-            for (int col = lane; col < kTW; col += 64) {
+            for (int col = lane; col < kTWb; col += 64) {
                 const int gx = tx0 + col;
                 uint32_t v = kNoPixel;
                 if (row_in && (uint32_t)gx < (uint32_t)a.W) v = a.depth[img_off + (size_t)gy * a.W + gx];
-                s_tile[r * kTW + col] = (uint16_t)v;
+                s_tile[r * kTWb + col] = (uint16_t)v;
             }
         }
         __syncthreads();
 
         if (!__any(live)) continue;   // wave-uniform; no barrier below this point in the iteration
         const int xl = x - tx0, yl = y - ty0;
-        const uint32_t d = live ? s_tile[yl * kTW + xl] : 1u;
+        const uint32_t d = live ? s_tile[yl * kTWb + xl] : 1u;
         const float df = (float)(d == 0u ? 1u : d);
         const float r0 = __builtin_amdgcn_rcpf(df);
         const float rcp = __builtin_fmaf(__builtin_fmaf(-df, r0, 1.0f), r0, r0);
         float rcp_s = rcp * (1.0f / kNumScale);
         const bool zero_depth = d == 0u;              // compute_feature returns 0.f (decision_tree_common.hpp:12)
-        const TileCtx pc = {reinterpret_cast<const char *>(a.depth) + img_off * 2, (uint32_t)kTW * 2u, (uint32_t)kTH,
-                            (uint32_t)kTW * 2u, (uint32_t)a.W * 2u, (uint32_t)a.H, (uint32_t)tx0 * 2u, (uint32_t)ty0};
+        const TileCtx pc = {reinterpret_cast<const char *>(a.depth) + img_off * 2, (uint32_t)kTWb * 2u, (uint32_t)kTHb,
+                            (uint32_t)kTWb * 2u, (uint32_t)a.W * 2u, (uint32_t)a.H, (uint32_t)tx0 * 2u, (uint32_t)ty0};
         uint32_t kx2 = ((uint32_t)xl - kMagicBits) * 2u;
         const uint32_t ky = (uint32_t)yl - kMagicBits;
         pin(kx2);
         if (all_fast) set_round_down(rcp_s);          // (the loop below has no other rounding arithmetic)
+        uint32_t *my_row = a.bits + (size_t)(live ? row : 0) * a.words;
 
-        uint32_t word = 0u;
-        for (int jb = 0; jb < a.P; jb += kBatch) {
-            TileProbe pu[kBatch], pv[kBatch];
-            float thr[kBatch];
+        uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+        for (int w = 0; w < words_used; ++w) {
+            uint32_t word = 0u;
+            const int j_end = min(a.P, w * 32 + 32);
+            for (int jb = w * 32; jb < j_end; jb += kBatch) {
+                TileProbe pu[kBatch], pv[kBatch];
+                float thr[kBatch];
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int j = min(jb + k, a.P - 1);               // tail: repeat the last proposal, result unused
-                uint32_t cux, cuy, cvx, cvy;
-                if (all_fast) {                                   // wave-uniform
-                    const float *p = nprops + (size_t)j * 5;
-                    thr[k] = p[4];
-                    const f2 nu = {p[0], p[1]}, nv = {p[2], p[3]}, r2 = {rcp_s, rcp_s}, m2 = {kMagic, kMagic};
-                    const f2 tu = __builtin_elementwise_fma(nu, r2, m2), tv = __builtin_elementwise_fma(nv, r2, m2);
-                    cux = (__float_as_uint(tu.x) << 1) + kx2; cuy = __float_as_uint(tu.y) + ky;
-                    cvx = (__float_as_uint(tv.x) << 1) + kx2; cvy = __float_as_uint(tv.y) + ky;
-                } else {
-                    const float *p = a.props + (size_t)j * 5;
-                    thr[k] = p[4];
-                    cux = (uint32_t)min(max(add_wrap(xl, floor_i32(p[0] / df)), -(1 << 30)), (1 << 30) - 1) * 2u;
-                    cuy = (uint32_t)add_wrap(yl, floor_i32(p[1] / df));
-                    cvx = (uint32_t)min(max(add_wrap(xl, floor_i32(p[2] / df)), -(1 << 30)), (1 << 30) - 1) * 2u;
-                    cvy = (uint32_t)add_wrap(yl, floor_i32(p[3] / df));
+                for (int k = 0; k < kBatch; ++k) {
+                    const int j = min(jb + k, a.P - 1);               // tail: repeat the last proposal, result unused
+                    uint32_t cux, cuy, cvx, cvy;
+                    if (all_fast) {                                   // wave-uniform
+                        const float *p = nprops + (size_t)j * 5;
+                        thr[k] = p[4];
+                        const f2 nu = {p[0], p[1]}, nv = {p[2], p[3]}, r2 = {rcp_s, rcp_s}, m2 = {kMagic, kMagic};
+                        const f2 tu = __builtin_elementwise_fma(nu, r2, m2), tv = __builtin_elementwise_fma(nv, r2, m2);
+                        cux = (__float_as_uint(tu.x) << 1) + kx2; cuy = __float_as_uint(tu.y) + ky;
+                        cvx = (__float_as_uint(tv.x) << 1) + kx2; cvy = __float_as_uint(tv.y) + ky;
+                    } else {
+                        const float *p = a.props + (size_t)j * 5;
+                        thr[k] = p[4];
+                        cux = (uint32_t)min(max(add_wrap(xl, floor_i32(p[0] / df)), -(1 << 30)), (1 << 30) - 1) * 2u;
+                        cuy = (uint32_t)add_wrap(yl, floor_i32(p[1] / df));
+                        cvx = (uint32_t)min(max(add_wrap(xl, floor_i32(p[2] / df)), -(1 << 30)), (1 << 30) - 1) * 2u;
+                        cvy = (uint32_t)add_wrap(yl, floor_i32(p[3] / df));
+                    }
+                    pu[k] = tprobe_issue(pc, cux, cuy);
+                    pv[k] = tprobe_issue(pc, cvx, cvy);
                 }
-                pu[k] = tprobe_issue(pc, cux, cuy);
-                pv[k] = tprobe_issue(pc, cvx, cvy);
-            }
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const float f = zero_depth ? 0.0f : (float)(tprobe_value(pu[k]) - tprobe_value(pv[k]));
-                const uint32_t left = (jb + k) < a.P && f < thr[k] ? 1u : 0u;      // tree_train.cu:57-58
-                word |= left << ((jb + k) & 31);
+                for (int k = 0; k < kBatch; ++k) {
+                    const float f = zero_depth ? 0.0f : (float)(tprobe_value(pu[k]) - tprobe_value(pv[k]));
+                    const uint32_t left = (jb + k) < a.P && f < thr[k] ? 1u : 0u;      // tree_train.cu:57-58
+                    word |= left << ((jb + k) & 31);
+                }
             }
-            if (((jb + kBatch) & 31) == 0 || jb + kBatch >= a.P) {     // (kBatch divides 32)
-                s_bits[tid * pitch + (jb >> 5)] = word;
-                word = 0u;
+            if (a.words < 4) {                         // (wave-uniform) rows of 8 bytes: word by word
+                if (live) my_row[w] = word;
+                continue;
+            }
+            const int slot = w & 3;
+            acc.x = slot == 0 ? word : acc.x; acc.y = slot == 1 ? word : acc.y;
+            acc.z = slot == 2 ? word : acc.z; acc.w = slot == 3 ? word : acc.w;
+            if (slot == 3 || w == words_used - 1) {    // 16 bytes of the row at a time (unused words of the last piece: zero)
+                if (live) *reinterpret_cast<uint4 *>(my_row + (w & ~3)) = acc;
+                acc = make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        if (all_fast) { pin(word); set_round_nearest(word); }
+        if (all_fast) { pin(acc.x); set_round_nearest(acc.x); }
         // words of the padding beyond P (rows are padded to a power of two)
-        for (int w = (a.P + 31) >> 5; w < a.words; ++w) s_bits[tid * pitch + w] = 0u;
-        // the wave's rows leave as whole lines (a wave only reads what its own lanes wrote: no barrier)
-        for (int r = 0; r < 64; ++r) {
-            const int dst = __shfl(row, r);
-            if (dst < 0) continue;                                     // wave-uniform
-            for (int w = lane; w < a.words; w += 64)
-                a.bits[(size_t)dst * a.words + w] = s_bits[(wave * 64 + r) * pitch + w];
+        if (live) {
+            if (a.words < 4) {
+                for (int w = words_used; w < a.words; ++w) my_row[w] = 0u;
+            } else {
+                for (int w = (words_used + 3) & ~3; w < a.words; w += 4)
+                    *reinterpret_cast<uint4 *>(my_row + w) = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
     }
     if (tid == 0) {   // every workgroup has made its final, failing pull before it gets here
@@ -978,17 +994,19 @@ int rdf_train_decision_bits(const uint16_t *depth, const int32_t *pos, int n_img
     a.n_tiles = (uint32_t)n_tiles;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    long long grid = (long long)cus * 4;
-    if (grid > n_tiles) grid = n_tiles;
     void *q = nullptr;
     if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_train_queue)) != hipSuccess || !q) return RDF_ERR_NO_DEVICE;
     const hipError_t eq = hipMemsetAsync(q, 0, sizeof(unsigned int) * 2, st);
     if (eq != hipSuccess) return (int)eq;
-    static_assert((kTH * kTW * 2) % 16 == 0, "the bit rows start 16-byte aligned behind the tile");
+    static_assert((kTHb * kTWb * 2) % 16 == 0, "the mailbox words sit aligned behind the tile");
     hipFuncAttributes fa;      // the probes address the tile as LDS address 0 + offset (TileCtx): no static LDS allowed
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_train_bits)) != hipSuccess || fa.sharedSizeBytes != 0)
         return RDF_ERR_NO_DEVICE;
-    const int lds = kTH * kTW * 2 + 256 * (a.words + 1) * 4 + 16;
+    const int lds = kTHb * kTWb * 2 + 16;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_train_bits, 256, (size_t)lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    long long grid = (long long)cus * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
     hipLaunchKernelGGL(k_train_bits, dim3((unsigned)grid), dim3(256), lds, st, a);
     return (int)hipGetLastError();
 }
