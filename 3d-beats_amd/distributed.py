@@ -164,13 +164,13 @@ class PeerCopyGather:
         self.errors = None
         # counters are read and written with small copies on a stream of their own (torch streams do not synchronise with the
         # default stream), so a poll never queues behind a forest launch; values come from a device table (index = value - 1)
-        self._poll_stream = torch.cuda.Stream()
-        self._host8 = torch.zeros(max(self.world + 1, 8) * self.n_slots * (self.FLAG_STRIDE // 8), dtype=torch.int64).pin_memory()
-        self._vals_base, self._vals = 0, torch.arange(1, 65537, dtype=torch.int64, device="cuda")
-        self._old_vals = []
         handle = [None]
         mine_ok, why = 1, None
         try:
+            self._poll_stream = torch.cuda.Stream()
+            self._host8 = torch.zeros(max(self.world + 1, 8) * self.n_slots * (self.FLAG_STRIDE // 8), dtype=torch.int64).pin_memory()
+            self._vals_base, self._vals = 0, torch.arange(1, 65537, dtype=torch.int64, device="cuda")
+            self._old_vals = []
             if self.rank == self.dst:
                 p = ctypes.c_void_p()
                 rc = self._lib.rdf_device_malloc(ctypes.byref(p), self.data_bytes_aligned + self.flag_bytes)
@@ -231,7 +231,7 @@ class PeerCopyGather:
                     rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self.slot_ptr(self.rank)), ctypes.c_void_p(pattern.data_ptr()),
                                                            n, ctypes.c_void_p(st))
                     if rc == 0:
-                        rc = self._signal(0, 0, st, value=0xA5)
+                        rc = self._signal(0, st, value=0xA5)
                     torch.cuda.synchronize()
             except Exception as e:      # noqa: BLE001
                 rc, why = -1, repr(e)
@@ -294,7 +294,7 @@ class PeerCopyGather:
             self.torch.cuda.synchronize()
         return self._vals.data_ptr() + 8 * (value - 1 - self._vals_base)
 
-    def _signal(self, step, which_rank_slot, stream, value=None):
+    def _signal(self, step, stream, value=None):
         """Stream-ordered: this rank's ready counter of `step`'s slot := step + 1 (a second small copy behind the data)."""
         return self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self._ready_ptr(step, self.rank)),
                                                  ctypes.c_void_p(self._value_ptr(int(step) + 1 if value is None else value)),
@@ -315,7 +315,7 @@ class PeerCopyGather:
         rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self.slot_ptr(self.rank, 0, step)), ctypes.c_void_p(src_ptr), int(nbytes),
                                                ctypes.c_void_p(stream))
         _lib.check(self._lib, rc, "rdf_memcpy_device_async (label maps)")
-        _lib.check(self._lib, self._signal(step, self.rank, stream), "rdf_memcpy_device_async (ready counter)")
+        _lib.check(self._lib, self._signal(step, stream), "rdf_memcpy_device_async (ready counter)")
 
     def wait_free(self, step, timeout_s=30.0, poll_s=50e-6):
         """Producer: block (host) until the consumer has released the step that last used `step`'s slot."""
