@@ -322,6 +322,9 @@ def test_device_trainer_fuzz_against_restatement(rdf, gpu_runtime):
         trainer = rdf.DecisionTreeTrainer(n, P)
         trainer.MAX_NEXT_NODES_TO_COUNT_PER_BLOCK = max_nodes
         trainer.allocate(ds, blocks * P, D)
+        # both ways of counting: rows of decision bits from the root on, from 4 or 16 active nodes on, or never
+        trainer.SORTED_ROWS_FROM_ACTIVE_NODES = int(rng.choice([1, 1, 4, 16]))
+        trainer.use_sorted_rows = bool(rng.random() < 0.8)
         tree = rdf.DecisionTree(D, C)
         seed = int(rng.integers(0, 2 ** 31))
         np.random.seed(seed)
