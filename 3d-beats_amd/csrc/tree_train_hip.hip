@@ -604,6 +604,8 @@ __global__ __launch_bounds__(256) void k_train_prepare_props(const float *props,
 // TA 66 % busy, VALU 45 %, nothing at its limit).
 constexpr int kHaloB = 32;      // (24, 40 and 48 measured the same on the 256-frame benchmark: 0.556-0.559 s)
 constexpr int kTWb = kCols + 2 * kHaloB, kTHb = kRows + 2 * kHaloB;
+constexpr int kBatchB = 4;      // proposals whose probes are in flight together (2: 0.567 s, 4: 0.556 s, 8: 0.552 s on the 256-frame benchmark)
+static_assert(32 % kBatchB == 0, "a word of decisions is a whole number of batches");
 
 __global__ __launch_bounds__(256) void k_train_bits(const BitsArgs a)
 {
@@ -671,11 +673,11 @@ __global__ __launch_bounds__(256) void k_train_bits(const BitsArgs a)
         for (int w = 0; w < words_used; ++w) {
             uint32_t word = 0u;
             const int j_end = min(a.P, w * 32 + 32);
-            for (int jb = w * 32; jb < j_end; jb += kBatch) {
-                TileProbe pu[kBatch], pv[kBatch];
-                float thr[kBatch];
+            for (int jb = w * 32; jb < j_end; jb += kBatchB) {
+                TileProbe pu[kBatchB], pv[kBatchB];
+                float thr[kBatchB];
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) {
+                for (int k = 0; k < kBatchB; ++k) {
                     const int j = min(jb + k, a.P - 1);               // tail: repeat the last proposal, result unused
                     uint32_t cux, cuy, cvx, cvy;
                     if (all_fast) {                                   // wave-uniform
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(256) void k_train_bits(const BitsArgs a)
                     pv[k] = tprobe_issue(pc, cvx, cvy);
                 }
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) {
+                for (int k = 0; k < kBatchB; ++k) {
                     const float f = zero_depth ? 0.0f : (float)(tprobe_value(pu[k]) - tprobe_value(pv[k]));
                     const uint32_t left = (jb + k) < a.P && f < thr[k] ? 1u : 0u;      // tree_train.cu:57-58
                     word |= left << ((jb + k) & 31);
