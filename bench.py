@@ -589,14 +589,22 @@ def main():
         return
 
     gather_mode = None if world == 1 else primary
+    # N = 1: `value` is the MEDIAN of the K per-step hipEvent times (SURVEY 8d's protocol), the K steps between the two
+    # barriers -- what the bench contract brackets -- are beside it as value_mean / ms_per_step_mean (they differ by a few
+    # tenths of a per cent).  N > 1: `value` is the bracketed K steps, MAX over ranks, gather included; a per-step median
+    # would leave the gather out, so it is reported for this rank's launches only (ms_per_step_median).
+    mean_ms = elapsed / a.steps * 1e3
+    if world == 1:
+        head = {"value": round(F * H * W / kern_med_ms / 1e3, 2), "ms_per_step": round(kern_med_ms, 4),
+                "value_mean": round(value, 2), "ms_per_step_mean": round(mean_ms, 4), "value_is": "median of the per-step times"}
+    else:
+        head = {"value": round(value, 2), "ms_per_step": round(mean_ms, 4), "ms_per_step_median": round(kern_med_ms, 4),
+                "value_is": "K steps between barriers, MAX over ranks, gather included"}
     out = {
         "metric": "classified Mpix/s on 848x480 depth frames (4 trees, depth 20); % HBM roofline",
-        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        # `value` and `ms_per_step` are the K steps between the two barriers (the bench contract); the median of the K
-        # per-step hipEvent times (SURVEY 8d's protocol) is beside them: this rank's launches, without the gather at N > 1
-        "ms_per_step_median": round(kern_med_ms, 4), "value_median": round(F * H * W / kern_med_ms / 1e3, 2),
+        "value": head.pop("value"), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": head.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", **head,
         "config": {"workload": f"{F} x {W}x{H} depth frames per GPU per step (config 4 shard = config 2 frame x {F}; "
                                f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
                                + (f"labels gathered to rank 0 ({gather_mode}; control plane {a.backend}) inside the timed region" if world > 1 else "1 GPU"),

@@ -34,6 +34,9 @@ def test_single_gpu_line_has_roofline_and_legs(tmp_path):
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "Mpix/s" and d["value"] > 0
     assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"]
+    # `value` is the median of the per-step times, the K steps between the barriers are beside it
+    assert d["value_is"].startswith("median") and d["value_mean"] > 0 and abs(d["value"] / d["value_mean"] - 1) < 0.2
+    assert abs(d["ms_per_step"] * d["value"] - 8 * 480 * 848 / 1e3) < 1e-2 * d["ms_per_step"] * d["value"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "levels", "algorithmic"} <= set(d["roofline"])
     assert d["roofline"]["algorithmic"]["bytes_per_launch"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and "differ in 0 pixels" in d["cpu_baseline"]["sample"]
