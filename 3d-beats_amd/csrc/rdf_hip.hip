@@ -19,18 +19,21 @@
 //   * all probes of a level are issued before any is consumed: nothing waits inside a divergent
 //     branch (an earlier version serialised eight global round trips per level that way);
 //   * the workgroup's depth tile plus a halo is staged in LDS (out-of-image cells = 65535), so
-//     most probes are LDS reads with no bounds check; far probes go to global memory;
+//     most probes are LDS reads with no bounds check; far probes go to global memory; the tile sits at LDS
+//     address 0 and x coordinates are kept doubled, so a probe's LDS address is one multiply-add;
 //   * tiles are handed to persistent workgroups by a device-side queue (one atomic per tile), so
 //     empty (background) tiles cost almost nothing and frames of unequal cost balance out;
 //   * the layers of a small layered run share ONE launch (workgroup b walks layer b % NL, unfiltered;
 //     the composite kernel applies the filters): one ramp and drain instead of one per layer.
 //
 // Bit-exactness: the reference computes floor((s*u)/d) with one fp32 multiply, one IEEE-correct
-// fp32 divide and __float2int_rd.  The fast path here (integer numerator, shared refined
-// reciprocal, one fma correction) is proven equal to that for every depth value and every
-// numerator it is used for by exhaustive GPU enumeration (tools/verify_*.hip); all other
-// numerators take hipcc's IEEE divide (never build this file with -ffast-math) followed by
-// v_floor_f32 + v_cvt_i32_f32.  Coordinate adds wrap, bounds are checked per axis.
+// fp32 divide and __float2int_rd.  The fast path here (integer numerator with a guard bit, the pixel's
+// refined reciprocal, ONE fma in round-toward-minus-infinity mode whose mantissa then holds the floor:
+// NodeRec16) is proven equal to that for every depth value and every numerator it is used for by
+// exhaustive GPU enumeration (tools/verify_magic.hip, tools/verify_intoffset.hip, tools/verify_fastdiv.hip);
+// all other numerators take hipcc's IEEE divide (never build this file with -ffast-math) followed by
+// v_floor_f32 + v_cvt_i32_f32.  Coordinate adds wrap, bounds are checked per axis.  The level loop runs with
+// the wave's rounding mode switched (s_setreg) and is written so that no other rounding arithmetic sits in it.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
