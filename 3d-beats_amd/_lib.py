@@ -92,6 +92,7 @@ SIGNATURES = {
     "rdf_set_layers_one_launch": (None, [_c_int]),
     "rdf_set_rows_per_wave": (None, [_c_int]),
     "rdf_set_force_exact": (None, [_c_int]),
+    "rdf_set_last_level_table": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),
     "rdf_event_record": (_c_int, [_c_void_p, _c_void_p]),
     "rdf_event_synchronize": (_c_int, [_c_void_p]),
@@ -102,7 +103,7 @@ SIGNATURES = {
     "rdf_error_string": (ctypes.c_char_p, [_c_int]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

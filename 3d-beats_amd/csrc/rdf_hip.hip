@@ -112,7 +112,18 @@ struct alignas(16) NodeRec32 {
     float thresh;
     uint32_t flags, pad0, pad1;
 };
-static_assert(sizeof(NodeRec16) == 16 && sizeof(NodeRec32) == 32, "record sizes");
+// Last-level record, 64 bytes (forests of up to four classes): the hot record of a node of level D-1 and the PDFs of
+// its two leaves in ONE half cache line.  A walk that reaches level D-1 ends there (tree_eval.cu:95-128), so its last
+// node fetch and its leaf fetch are the same 128-byte line: fetched together they are one L1 fill instead of two
+// (leaf loads were 6.5 % of the batch's time, profiles/r03_*).  The table is used when every record of it is an
+// ordinary node with two leaves (flags == both leaves, no kFlagExact; untrained all-zero nodes are such nodes);
+// k_pack counts the others behind the table and the kernel takes the general path when the count is not zero.
+struct alignas(64) LastLevelRec {
+    NodeRec16 node;
+    float pdf_left[4], pdf_right[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(NodeRec16) == 16 && sizeof(NodeRec32) == 32 && sizeof(LastLevelRec) == 64, "record sizes");
 
 struct EvalArgs {
     const uint16_t *depth;
@@ -142,6 +153,7 @@ struct EvalArgs {
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
+    const uint4 *last_level;   // LastLevelRec [T][2^(D-1)] followed by the count of records that rule the table out, or null
     int cpad;                  // classes rounded up to a multiple of 4
     int filter_class;
     int check_empty;       // look at a tile's centre depths before staging it (throughput shape)
@@ -303,6 +315,12 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
     // ---- stage the top K levels of every tree.  Tables use 1-based heap numbering (slot 0 unused):
     // node h has children 2h and 2h+1, which therefore share one aligned 32-byte pair ----
     const uint32_t lds_pitch = 1u << K;   // records per tree in LDS
+    // (LastLevelRec) level D-1 is walked from the last-level table when the forest has a usable one
+    constexpr bool kLastLevelTable = PACKED && CMAX == 4 && !TW;
+    bool last_from_table = false;
+    if (kLastLevelTable && a.last_level)
+        last_from_table = *reinterpret_cast<const uint32_t *>(a.last_level + (((size_t)a.T << (a.D - 1)) << 2)) == 0u;
+    const int walk_levels = last_from_table ? a.D - 1 : a.D;
     for (uint32_t i = tid; i < (uint32_t)a.T * lds_pitch; i += BLOCK) {
         const uint32_t k = i >> K, h = i & (lds_pitch - 1u);
         if (h == 0u) continue;
@@ -603,7 +621,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                     const bool fast_levels = PACKED || K > 0;
                     if (fast_levels) set_round_down(rcp_s);
 
-                    for (int j = 0; j < a.D; ++j) {
+                    for (int j = 0; j < walk_levels; ++j) {
                         bool any = false;
 #pragma unroll
                         for (int k = 0; k < GROUP; ++k) any |= (int)h[k] > 0;
@@ -723,6 +741,60 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             h[k] = walking ? next : h[k];
                         }
                     }
+                    // ---- level D-1 from the last-level table, one tree after the other: the node and both leaf PDFs of a
+                    // tree come with one line fill and the side taken picks the PDF (every record of a usable table is an
+                    // ordinary node with two leaves: no IEEE divide, no "continue").  The PDF of each tree -- from the
+                    // table, or from the PDF table for a walk that ended higher up -- is added at once, in tree order
+                    // (the canonical order), in round-to-nearest: the mode goes back and forth per tree ----
+                    if (kLastLevelTable && last_from_table) {
+                        const uint32_t first = 1u << (a.D - 1);
+#pragma unroll
+                        for (int k = 0; k < GROUP; ++k) {
+                            const bool walking = (int)h[k] > 0;
+                            float4 sel = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (__any(walking)) {
+                                const uint32_t hn = (uint32_t)max((int)h[k], (int)first);
+                                const int tk = min(kb + k, a.T - 1);
+                                const uint4 *rec = a.last_level + ((((size_t)tk << (a.D - 1)) + (hn - first)) << 2);
+                                const Node n = decode_node(rec[0]);
+                                const float4 pl = *reinterpret_cast<const float4 *>(rec + 1);
+                                const float4 pr = *reinterpret_cast<const float4 *>(rec + 2);
+                                const f2 nu = {n.ax, n.ay};
+                                const f2 nv = {n.bx, n.by};
+                                const f2 r2 = {rcp_s, rcp_s};
+                                const f2 m2 = {kMagic, kMagic};
+                                const f2 tu = __builtin_elementwise_fma(nu, r2, m2);
+                                const f2 tv = __builtin_elementwise_fma(nv, r2, m2);
+                                const TileProbe qu = tprobe_issue(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky);
+                                const TileProbe qv = tprobe_issue(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky);
+                                if (STATS && c0 == 0) st_lv += walking ? 1u : 0u;
+                                const int g = tprobe_value(qu) - tprobe_value(qv) - (int)n.lo16;
+                                const uint32_t next = walk_step(h[k], g, n.w2, n.flags);
+                                const bool right = (next & 1u) != 0u;
+                                sel = make_float4(right ? pr.x : pl.x, right ? pr.y : pl.y, right ? pr.z : pl.z, right ? pr.w : pl.w);
+                            }
+                            pin(sel.x); pin(sel.y); pin(sel.z); pin(sel.w);
+                            set_round_nearest(sel.x);
+                            pin(sel.y); pin(sel.z); pin(sel.w);
+                            if (walking) {
+                                pdf[0] = pdf[0] + sel.x; pdf[1] = pdf[1] + sel.y;
+                                pdf[2] = pdf[2] + sel.z; pdf[3] = pdf[3] + sel.w;
+                                any_leaf = true;
+                                if (STATS && c0 == 0) st_lf++;
+                            } else if (add_leaf_pdf(h[k], kb + k, c0, pdf)) {
+                                any_leaf = true;
+                                if (STATS && c0 == 0) st_lf++;
+                            }
+                            if (k + 1 < GROUP) {
+#pragma unroll
+                                for (int c = 0; c < CMAX; ++c) pin(pdf[c]);
+                                set_round_down(pdf[0]);
+#pragma unroll
+                                for (int c = 1; c < CMAX; ++c) pin(pdf[c]);
+                            }
+                        }
+                        continue;       // (next group of trees; the mode is round-to-nearest)
+                    }
                     // back to round-to-nearest for the sums of leaf PDFs (tied to the walk's results)
                     if (fast_levels) {
 #pragma unroll
@@ -820,7 +892,8 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 
 // ---- load-time repack: one thread per node; writes the 16-byte and the 32-byte table ----
 __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, NodeRec32 *packed32,
-                                              float *packed_pdf, int C, int cpad,
+                                              float *packed_pdf, LastLevelRec *last_level, unsigned int *last_level_unusable,
+                                              int C, int cpad,
                                               size_t total_slots, int D, int E, float s, int force_exact)
 {
     // slot = tree * 2^D + h, h = 1-based heap index (slot h == 0 of each tree is unused and zeroed)
@@ -850,6 +923,18 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     for (int c = 0; c < cpad; ++c) {
         q[c] = c < C ? p[7 + c] : 0.f;
         q[cpad + c] = c < C ? p[7 + C + c] : 0.f;
+    }
+    const size_t first = (size_t)1 << (D - 1);
+    if (last_level && h >= first) {     // (LastLevelRec; cpad == 4)
+        LastLevelRec r;
+        r.node = h16;
+        for (int c = 0; c < 4; ++c) {
+            r.pdf_left[c] = q[c];
+            r.pdf_right[c] = q[4 + c];
+            r.pad[c] = 0u;
+        }
+        last_level[(tree << (D - 1)) + (h - first)] = r;
+        if ((n.flags & 7u) != (kFlagLeftLeaf | kFlagRightLeaf)) atomicAdd(last_level_unusable, 1u);
     }
 }
 
@@ -1268,12 +1353,23 @@ int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void 
     return 0;
 }
 
+static int classes_padded(int n_classes) { return (n_classes + 3) & ~3; }
+
+// the last-level table (LastLevelRec) behind the three per-slot tables, and the 64 bytes that hold its count of unusable
+// records: forests of one to four classes and two or more levels
+static size_t last_level_bytes(int n_trees, int max_depth, int n_classes)
+{
+    if (classes_padded(n_classes) != 4 || max_depth < 2 || n_trees < 1) return 0;
+    return ((size_t)n_trees << (max_depth - 1)) * sizeof(LastLevelRec) + 64;
+}
+
 Knob g_halo{-1};
 Knob g_lds_levels{-1};
 Knob g_tree_waves{-1};
 Knob g_stage_vec{-1};
 Knob g_rows_per_wave{0};
 Knob g_force_exact{0};
+Knob g_last_level_table{-1};                    // -1/1: level D-1 from the last-level table when the forest has one; 0: never
 
 // What eval_common works out before it launches: the kernel arguments (without a queue slot), the dynamic LDS and the
 // geometry.  layered_run asks for the plan only (plan_only) to put several layers into one launch.
@@ -1433,6 +1529,12 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     while (K < max_depth && (k_forced < 0 || K < k_forced) &&
            (long long)n_trees * (1ll << (K + 1)) * 16 + tile_bytes + 32 + list_bytes <= budget) ++K;
     a.lds_levels = K;
+    // level D-1 from the last-level table (LastLevelRec) when the forest was packed with one and that level is not in LDS
+    const int llt_knob = g_last_level_table;
+    const int want_llt = llt_knob >= 0 ? llt_knob : env_int("RDF_LAST_LEVEL_TABLE", 1);
+    if (packed && want_llt != 0 && !tw && max_depth - 1 >= K && last_level_bytes(n_trees, max_depth, n_classes) != 0)
+        a.last_level = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.packed_pdf) +
+                                                       ((size_t)n_trees << max_depth) * 2 * (size_t)a.cpad * sizeof(float));
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
     a.lds_nodes_off = (uint32_t)tile_bytes;
     a.lds_mail_off = (uint32_t)(tile_bytes + node_bytes);
@@ -1492,13 +1594,12 @@ int rdf_eval_tree(const uint16_t *depth, int n_img, int dim_x, int dim_y, const 
                        labels_out, 1, 1.0f, 1, nullptr, stream);
 }
 
-static int classes_padded(int n_classes) { return (n_classes + 3) & ~3; }
-
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes)
 {
     if (n_trees < 0 || max_depth < 0 || max_depth > 30 || n_classes < 0) return 0;
     return ((size_t)n_trees << max_depth) *
-           (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float));
+           (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float)) +
+           last_level_bytes(n_trees, max_depth, n_classes);
 }
 
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes, float scale_factor,
@@ -1511,11 +1612,21 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
     if (!forest || !packed) return RDF_ERR_NULL_PTR;
     const size_t blocks = (total + 255) / 256;
     if (blocks >= (1ull << 31)) return RDF_ERR_TOO_LARGE;
+    char *tail = reinterpret_cast<char *>(packed) +
+                 total * (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float));
+    LastLevelRec *last_level = nullptr;
+    unsigned int *unusable = nullptr;
+    if (last_level_bytes(n_trees, max_depth, n_classes) != 0) {
+        last_level = reinterpret_cast<LastLevelRec *>(tail);
+        unusable = reinterpret_cast<unsigned int *>(last_level + ((size_t)n_trees << (max_depth - 1)));
+        const hipError_t e = hipMemsetAsync(unusable, 0, 64, reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        forest, reinterpret_cast<NodeRec16 *>(packed),
                        reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total),
                        reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32))),
-                       n_classes, classes_padded(n_classes), total,
+                       last_level, unusable, n_classes, classes_padded(n_classes), total,
                        max_depth, 7 + 2 * n_classes, scale_factor, (int)g_force_exact);
     return (int)hipGetLastError();
 }
@@ -1726,6 +1837,7 @@ void rdf_set_tree_waves(int mode) { g_tree_waves = mode; }
 void rdf_set_stage_vec(int on) { g_stage_vec = on; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }
+void rdf_set_last_level_table(int on) { g_last_level_table = on; }
 
 int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved)
 {

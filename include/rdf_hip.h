@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RDF_ABI_VERSION 1
+#define RDF_ABI_VERSION 2
 
 #define RDF_OK 0
 #define RDF_ERR_BAD_ARG (-1)     /* negative size, labels_reduce < 1, max_depth outside [0,30] ... */
@@ -119,6 +119,10 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
  * src/decision_tree.py:148-158.  The packed tables depend on scale_factor and must be rebuilt
  * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes
  * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
+ * Forests of up to four classes and two or more levels carry a fourth table behind those three: one 64-byte record per
+ * node of the deepest level, {hot record, left PDF, right PDF}, and a 64-byte trailer whose first word counts the
+ * records that are not ordinary nodes with two leaves.  When that count is zero a walk takes its last node and its leaf
+ * PDF from one cache line (rdf_set_last_level_table); otherwise the table is ignored.
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
@@ -334,6 +338,9 @@ void rdf_set_layers_one_launch(int on);  /* rdf_layered_run on a small launch ev
                                             stack unfiltered in ONE launch and filters in the composite kernel: 1/-1 (default) on, 0 off */
 void rdf_set_stage_vec(int on);          /* tile staging with 16-byte loads where alignment allows: 1/-1 (default) on, 0 off */
 void rdf_set_force_exact(int on);        /* test knob: rdf_forest_pack flags every node for the IEEE-divide path */
+void rdf_set_last_level_table(int on);   /* -1/1: packed forests of up to four classes walk level D-1 from the table that
+                                            holds a node and both its leaf PDFs in one half line (when every node of that
+                                            level is an ordinary one with two leaves); 0: never */
 
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
 int rdf_event_create(void **event);

@@ -36,7 +36,7 @@ class _OracleLib:
         return 0 if rc == 0 else -1
 
     def rdf_forest_packed_bytes(self, T, D, C):
-        return (T << D) * (48 + 8 * ((C + 3) & ~3))
+        return (T << D) * (48 + 8 * ((C + 3) & ~3)) + ((T << (D - 1)) * 64 + 64 if 1 <= C <= 4 and D >= 2 and T >= 1 else 0)
 
     def rdf_forest_pack(self, forest, T, D, C, s, packed, stream):
         self.calls.append(("rdf_forest_pack", T, D, C, float(s)))

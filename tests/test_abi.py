@@ -37,7 +37,9 @@ def test_binding_table_matches_header(rdf):
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
     assert lib.rdf_abi_version() == _lib.ABI_VERSION
-    assert lib.rdf_forest_packed_bytes(4, 20, 4) == (4 << 20) * (48 + 32)
+    # three tables per heap slot; up to four classes: the 64-byte records of the deepest level and a 64-byte trailer
+    assert lib.rdf_forest_packed_bytes(4, 20, 4) == (4 << 20) * (48 + 32) + (4 << 19) * 64 + 64
+    assert lib.rdf_forest_packed_bytes(2, 1, 3) == (2 << 1) * (48 + 32)
     assert lib.rdf_forest_packed_bytes(3, 10, 5) == (3 << 10) * (48 + 64)
     assert b"2^31" in lib.rdf_error_string(-3)
 

@@ -960,3 +960,49 @@ def test_three_layer_stack_matches_oracle(r, s, rdf, gpu_runtime, oracle):
             assert np.array_equal(got.cu().get(), want[0]), f"fused={fused}"
         assert np.array_equal(lbuf.cu().get(), comp[0]), f"fused={fused}"
     assert lf.eval.composite_bad_pixels() == 0
+
+
+@pytest.mark.parametrize("spoil", ["none", "continue_flag", "huge_numerator", "nan_child"])
+@pytest.mark.parametrize("trees,levels,classes,topology", [(4, 9, 4, "full"), (4, 10, 4, "trained"), (3, 9, 3, "trained"), (8, 9, 2, "full"),
+                                                          (1, 8, 1, "full"), (2, 2, 4, "full")])
+def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_one(trees, levels, classes, topology, spoil,
+                                                                                    rdf, gpu_runtime, oracle):
+    """Packed forests of up to four classes hold the nodes of level D-1 with both their leaf PDFs in 64-byte records
+    (include/rdf_hip.h, rdf_forest_pack).  The table's trailer counts the records it cannot serve -- a child flag that says
+    "continue" (tree_eval.cu:101-102 with -1 at the last level: no contribution), a numerator for the IEEE divide -- and one
+    such record sends the whole forest down the general path.  Either way, and with the knob off: the oracle's labels, on a
+    batch that fills the chip (512-thread workgroups) and on a small one."""
+    synth = rdf.synth
+    rng = np.random.default_rng(5 + trees * 100 + levels)
+    f_np = synth.forest(trees, levels, classes, topology, 700 + trees)
+    first = (1 << (levels - 1)) - 1                     # 0-based index of the first node of level D-1
+    f_np[:, first:, 7:] = rng.random((trees, first + 1, 2 * classes), dtype=np.float32)     # left and right PDFs tell sides apart
+    k, node = trees - 1, first + int(rng.integers(0, first + 1))
+    if spoil == "continue_flag":
+        f_np[k, node, 5] = -1.0
+    elif spoil == "huge_numerator":
+        f_np[k, node, 2] = 3.0e7
+    elif spoil == "nan_child":                          # NaN is not in [-1, 0): a leaf like any other
+        f_np[k, node, 6] = np.nan
+    lib = gpu_runtime.lib
+    forest = rdf.DecisionForest.from_numpy(f_np)
+    packed = forest.packed(1.0)
+    gpu_runtime.synchronize()
+    slots = trees << levels
+    trailer = slots * (48 + 32) + (trees << (levels - 1)) * 64
+    assert packed.nbytes == trailer + 64
+    unusable = int(packed.get()[trailer:trailer + 4].view(np.uint32)[0])
+    assert unusable == (1 if spoil in ("continue_flag", "huge_numerator") else 0)
+    for n, h, w in ((40, 240, 424), (2, 70, 90)):
+        frames = synth.frames(["dense", "live"] * (n // 2), 31 + n, h, w)
+        want = np.full(frames.shape, 65535, np.uint16)
+        oracle.eval_forest(frames, f_np, want)
+        depth = rdf.to_device(frames)
+        for knob in (1, 0):
+            lib.rdf_set_last_level_table(knob)
+            try:
+                labels = rdf.DeviceArray(frames.shape, np.uint16).fill(65535)
+                rdf.DecisionTreeEvaluator(use_packed=True).get_labels_forest(forest, depth, labels)
+                assert np.array_equal(labels.get(), want), (n, knob, int((labels.get() != want).sum()))
+            finally:
+                lib.rdf_set_last_level_table(-1)
