@@ -153,7 +153,8 @@ struct EvalArgs {
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
-    const uint4 *last_level;   // LastLevelRec [T][2^(D-1)] followed by the count of records that rule the table out, or null
+    const uint4 *last_level;   // LastLevelRec [T][2^(D-1)] followed by the trailer (see k_pack), or null
+    uint32_t last_level_min;   // deepest-level nodes in use from which the table is taken
     int cpad;                  // classes rounded up to a multiple of 4
     int filter_class;
     int check_empty;       // look at a tile's centre depths before staging it (throughput shape)
@@ -318,8 +319,13 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
     // (LastLevelRec) level D-1 is walked from the last-level table when the forest has a usable one
     constexpr bool kLastLevelTable = PACKED && CMAX == 4 && !TW;
     bool last_from_table = false;
-    if (kLastLevelTable && a.last_level)
-        last_from_table = *reinterpret_cast<const uint32_t *>(a.last_level + (((size_t)a.T << (a.D - 1)) << 2)) == 0u;
+    if (kLastLevelTable && a.last_level) {
+        // the trailer's words: every record usable, and the forest uses at least a.last_level_min of its deepest nodes (a
+        // forest whose walks mostly end higher up is better off with the general path: its leaf rows come in one round
+        // trip for the group, the table walks level D-1 tree after tree)
+        const uint2 t = *reinterpret_cast<const uint2 *>(a.last_level + (((size_t)a.T << (a.D - 1)) << 2));
+        last_from_table = t.x == 0u && t.y >= a.last_level_min;
+    }
     const int walk_levels = last_from_table ? a.D - 1 : a.D;
     for (uint32_t i = tid; i < (uint32_t)a.T * lds_pitch; i += BLOCK) {
         const uint32_t k = i >> K, h = i & (lds_pitch - 1u);
@@ -743,22 +749,33 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                     }
                     // ---- level D-1 from the last-level table, one tree after the other: the node and both leaf PDFs of a
                     // tree come with one line fill and the side taken picks the PDF (every record of a usable table is an
-                    // ordinary node with two leaves: no IEEE divide, no "continue").  The PDF of each tree -- from the
-                    // table, or from the PDF table for a walk that ended higher up -- is added at once, in tree order
-                    // (the canonical order), in round-to-nearest: the mode goes back and forth per tree ----
+                    // ordinary node with two leaves: no IEEE divide, no "continue").  A lane whose walk ended higher up
+                    // points the same two PDF loads at its leaf in the PDF table instead, so the PDFs of a tree arrive together
+                    // and are added at once, in tree order (the canonical order), in round-to-nearest: the mode goes back and
+                    // forth per tree.  (A wave with no lane at level D-1 takes the general path below.) ----
                     if (kLastLevelTable && last_from_table) {
-                        const uint32_t first = 1u << (a.D - 1);
+                        bool any_w = false;
 #pragma unroll
-                        for (int k = 0; k < GROUP; ++k) {
-                            const bool walking = (int)h[k] > 0;
-                            float4 sel = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (__any(walking)) {
+                        for (int k = 0; k < GROUP; ++k) any_w |= (int)h[k] > 0;
+                        if (__any(any_w)) {
+                            const uint32_t first = 1u << (a.D - 1);
+#pragma unroll
+                            for (int k = 0; k < GROUP; ++k) {
+                                const bool walking = (int)h[k] > 0;
+                                const bool ended = (int)h[k] < 0 && h[k] != kIdle;      // at a leaf above level D-1
                                 const uint32_t hn = (uint32_t)max((int)h[k], (int)first);
                                 const int tk = min(kb + k, a.T - 1);
                                 const uint4 *rec = a.last_level + ((((size_t)tk << (a.D - 1)) + (hn - first)) << 2);
-                                const Node n = decode_node(rec[0]);
-                                const float4 pl = *reinterpret_cast<const float4 *>(rec + 1);
-                                const float4 pr = *reinterpret_cast<const float4 *>(rec + 2);
+                                // PDF table, 16-byte rows: ((tree << D) + node) * 2 + side = (tree << (D + 1)) + (h & ~kDone), see add_leaf_pdf
+                                const uint4 *leaf = reinterpret_cast<const uint4 *>(a.packed_pdf) + (((size_t)tk << (a.D + 1)) + (h[k] & ~kDone));
+                                const uint4 *pp = ended ? leaf : rec + 1;
+                                uint4 w = rec[0];
+                                float4 pa = *reinterpret_cast<const float4 *>(pp);
+                                float4 pb = *reinterpret_cast<const float4 *>(pp + 1);
+                                // (the three loads are issued together -- a record's line is filled once -- and nothing is
+                                // scheduled between the node's arrival and the PDFs' issue)
+                                asm volatile("" : "+v"(w.x), "+v"(pa.x), "+v"(pb.x));
+                                const Node n = decode_node(w);
                                 const f2 nu = {n.ax, n.ay};
                                 const f2 nv = {n.bx, n.by};
                                 const f2 r2 = {rcp_s, rcp_s};
@@ -770,30 +787,27 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                 if (STATS && c0 == 0) st_lv += walking ? 1u : 0u;
                                 const int g = tprobe_value(qu) - tprobe_value(qv) - (int)n.lo16;
                                 const uint32_t next = walk_step(h[k], g, n.w2, n.flags);
-                                const bool right = (next & 1u) != 0u;
-                                sel = make_float4(right ? pr.x : pl.x, right ? pr.y : pl.y, right ? pr.z : pl.z, right ? pr.w : pl.w);
-                            }
-                            pin(sel.x); pin(sel.y); pin(sel.z); pin(sel.w);
-                            set_round_nearest(sel.x);
-                            pin(sel.y); pin(sel.z); pin(sel.w);
-                            if (walking) {
-                                pdf[0] = pdf[0] + sel.x; pdf[1] = pdf[1] + sel.y;
-                                pdf[2] = pdf[2] + sel.z; pdf[3] = pdf[3] + sel.w;
-                                any_leaf = true;
-                                if (STATS && c0 == 0) st_lf++;
-                            } else if (add_leaf_pdf(h[k], kb + k, c0, pdf)) {
-                                any_leaf = true;
-                                if (STATS && c0 == 0) st_lf++;
-                            }
-                            if (k + 1 < GROUP) {
+                                const bool right = walking && (next & 1u) != 0u;
+                                float4 sel = make_float4(right ? pb.x : pa.x, right ? pb.y : pa.y, right ? pb.z : pa.z, right ? pb.w : pa.w);
+                                pin(sel.x); pin(sel.y); pin(sel.z); pin(sel.w);
+                                set_round_nearest(sel.x);
+                                pin(sel.y); pin(sel.z); pin(sel.w);
+                                if (walking || ended) {
+                                    pdf[0] = pdf[0] + sel.x; pdf[1] = pdf[1] + sel.y;
+                                    pdf[2] = pdf[2] + sel.z; pdf[3] = pdf[3] + sel.w;
+                                    any_leaf = true;
+                                    if (STATS && c0 == 0) st_lf++;
+                                }
+                                if (k + 1 < GROUP) {
 #pragma unroll
-                                for (int c = 0; c < CMAX; ++c) pin(pdf[c]);
-                                set_round_down(pdf[0]);
+                                    for (int c = 0; c < CMAX; ++c) pin(pdf[c]);
+                                    set_round_down(pdf[0]);
 #pragma unroll
-                                for (int c = 1; c < CMAX; ++c) pin(pdf[c]);
+                                    for (int c = 1; c < CMAX; ++c) pin(pdf[c]);
+                                }
                             }
+                            continue;       // (next group of trees; the mode is round-to-nearest)
                         }
-                        continue;       // (next group of trees; the mode is round-to-nearest)
                     }
                     // back to round-to-nearest for the sums of leaf PDFs (tied to the walk's results)
                     if (fast_levels) {
@@ -806,11 +820,34 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 
                     if (TW) { tw_h = h[0]; break; }       // the trees meet in LDS, below the pixel loop
                     // leaf PDFs, strictly in tree order (canonical sum order)
+                    if (PACKED && CMAX == 4) {
+                        // the group's PDF rows are fetched together (a lane without a leaf in a tree reads the table's
+                        // first row and drops it) and then added in order: one round trip, not one per tree
+                        float4 row[GROUP];
 #pragma unroll
-                    for (int k = 0; k < GROUP; ++k) {
-                        if (add_leaf_pdf(h[k], kb + k, c0, pdf)) {
-                            any_leaf = true;
-                            if (STATS && c0 == 0) st_lf++;
+                        for (int k = 0; k < GROUP; ++k) {
+                            const bool ended = (int)h[k] < 0 && h[k] != kIdle;
+                            const int tk = min(kb + k, a.T - 1);
+                            // 16-byte rows: (((tree << D) + node) * 2 + side) * (cpad / 4) + c0 / 4, node * 2 + side = h & ~kDone (add_leaf_pdf)
+                            const size_t at = ((((size_t)tk << (a.D + 1)) + (h[k] & ~kDone)) * (size_t)(a.cpad >> 2)) + (size_t)(c0 >> 2);
+                            row[k] = reinterpret_cast<const float4 *>(a.packed_pdf)[ended ? at : 0];
+                        }
+#pragma unroll
+                        for (int k = 0; k < GROUP; ++k) {
+                            if ((int)h[k] < 0 && h[k] != kIdle) {
+                                pdf[0] = pdf[0] + row[k].x; pdf[1] = pdf[1] + row[k].y;
+                                pdf[2] = pdf[2] + row[k].z; pdf[3] = pdf[3] + row[k].w;
+                                any_leaf = true;
+                                if (STATS && c0 == 0) st_lf++;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < GROUP; ++k) {
+                            if (add_leaf_pdf(h[k], kb + k, c0, pdf)) {
+                                any_leaf = true;
+                                if (STATS && c0 == 0) st_lf++;
+                            }
                         }
                     }
                 }
@@ -934,7 +971,18 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
             r.pad[c] = 0u;
         }
         last_level[(tree << (D - 1)) + (h - first)] = r;
-        if ((n.flags & 7u) != (kFlagLeftLeaf | kFlagRightLeaf)) atomicAdd(last_level_unusable, 1u);
+        // trailer word 0: records the table cannot serve; word 1: records whose parent says "continue" on their side (how
+        // much of level D-1 the forest uses at all).  One atomic per wave and word.
+        const bool unusable = (n.flags & 7u) != (kFlagLeftLeaf | kFlagRightLeaf);
+        const float *pp = forest + (tree * ((((size_t)1) << D) - 1) + ((h >> 1) - 1)) * (size_t)E;
+        const float to_me = pp[5 + (h & 1)];
+        const bool in_use = to_me >= -1.0f && to_me < 0.0f;
+        const unsigned long long bu = __ballot(unusable), bi = __ballot(in_use);
+        const unsigned long long mine = __ballot(true);
+        if ((unsigned)__lane_id() == (unsigned)__ffsll((long long)mine) - 1u) {
+            if (bu) atomicAdd(last_level_unusable, (unsigned)__popcll(bu));
+            if (bi) atomicAdd(last_level_unusable + 1, (unsigned)__popcll(bi));
+        }
     }
 }
 
@@ -1369,7 +1417,7 @@ Knob g_tree_waves{-1};
 Knob g_stage_vec{-1};
 Knob g_rows_per_wave{0};
 Knob g_force_exact{0};
-Knob g_last_level_table{-1};                    // -1/1: level D-1 from the last-level table when the forest has one; 0: never
+Knob g_last_level_table{-1};                    // -1: level D-1 from the last-level table when it is usable and the forest uses half of that level; 1: whenever usable; 0: never
 
 // What eval_common works out before it launches: the kernel arguments (without a queue slot), the dynamic LDS and the
 // geometry.  layered_run asks for the plan only (plan_only) to put several layers into one launch.
@@ -1532,9 +1580,13 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // level D-1 from the last-level table (LastLevelRec) when the forest was packed with one and that level is not in LDS
     const int llt_knob = g_last_level_table;
     const int want_llt = llt_knob >= 0 ? llt_knob : env_int("RDF_LAST_LEVEL_TABLE", 1);
-    if (packed && want_llt != 0 && !tw && max_depth - 1 >= K && last_level_bytes(n_trees, max_depth, n_classes) != 0)
+    if (packed && want_llt != 0 && !tw && max_depth - 1 >= K && last_level_bytes(n_trees, max_depth, n_classes) != 0) {
         a.last_level = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.packed_pdf) +
                                                        ((size_t)n_trees << max_depth) * 2 * (size_t)a.cpad * sizeof(float));
+        // from which share of level D-1 in use (see k_pack) on: by default half; knob 1 = whenever the table is usable
+        const int pct = llt_knob == 1 ? 0 : env_int("RDF_LAST_LEVEL_MIN_PCT", 50);
+        a.last_level_min = (uint32_t)((((unsigned long long)n_trees << (max_depth - 1)) * (unsigned long long)(pct < 0 ? 0 : pct > 100 ? 100 : pct)) / 100u);
+    }
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
     a.lds_nodes_off = (uint32_t)tile_bytes;
     a.lds_mail_off = (uint32_t)(tile_bytes + node_bytes);

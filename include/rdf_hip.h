@@ -120,9 +120,10 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
  * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes
  * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
  * Forests of up to four classes and two or more levels carry a fourth table behind those three: one 64-byte record per
- * node of the deepest level, {hot record, left PDF, right PDF}, and a 64-byte trailer whose first word counts the
- * records that are not ordinary nodes with two leaves.  When that count is zero a walk takes its last node and its leaf
- * PDF from one cache line (rdf_set_last_level_table); otherwise the table is ignored.
+ * node of the deepest level, {hot record, left PDF, right PDF}, and a 64-byte trailer: word 0 counts the records that
+ * are not ordinary nodes with two leaves, word 1 the records whose parent continues to them.  When word 0 is zero and
+ * word 1 is at least half the level, a walk takes its last node and its leaf PDF from one cache line
+ * (rdf_set_last_level_table); otherwise the table is ignored.
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
@@ -338,9 +339,11 @@ void rdf_set_layers_one_launch(int on);  /* rdf_layered_run on a small launch ev
                                             stack unfiltered in ONE launch and filters in the composite kernel: 1/-1 (default) on, 0 off */
 void rdf_set_stage_vec(int on);          /* tile staging with 16-byte loads where alignment allows: 1/-1 (default) on, 0 off */
 void rdf_set_force_exact(int on);        /* test knob: rdf_forest_pack flags every node for the IEEE-divide path */
-void rdf_set_last_level_table(int on);   /* -1/1: packed forests of up to four classes walk level D-1 from the table that
-                                            holds a node and both its leaf PDFs in one half line (when every node of that
-                                            level is an ordinary one with two leaves); 0: never */
+void rdf_set_last_level_table(int on);   /* packed forests of up to four classes can walk level D-1 from the table that holds
+                                            a node and both its leaf PDFs in one half line.  -1: when every node of that level
+                                            is an ordinary one with two leaves AND the forest uses at least half of the level
+                                            (walks that mostly end higher up gain nothing); 1: whenever the nodes allow it;
+                                            0: never */
 
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
 int rdf_event_create(void **event);

@@ -417,6 +417,7 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
             lib.rdf_set_scheduler(int(rng.choice([-1, 0, 1, 2])))
             lib.rdf_set_lds_budget_bytes(int(rng.choice([0, 1, 9000, 40000, 120000])))
             lib.rdf_set_tree_waves(int(rng.choice([-1, -1, 0, 1])))
+            lib.rdf_set_last_level_table(int(rng.choice([-1, -1, 0])))
             want = np.full((n, h // r, w // r), prefill, np.uint16)
             oracle.eval_forest(depth, forest, want, r, filt, 2 if use_filter else None, s)
             for path in ("packed", "direct"):
@@ -432,6 +433,7 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
         lib.rdf_set_scheduler(-1)
         lib.rdf_set_lds_budget_bytes(0)
         lib.rdf_set_tree_waves(-1)
+        lib.rdf_set_last_level_table(-1)
 
 
 @pytest.mark.parametrize("trees,classes,r,topology", [(4, 4, 2, "full"), (4, 4, 1, "trained"), (3, 9, 2, "trained"), (2, 20, 1, "full"),
@@ -970,8 +972,9 @@ def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_o
     """Packed forests of up to four classes hold the nodes of level D-1 with both their leaf PDFs in 64-byte records
     (include/rdf_hip.h, rdf_forest_pack).  The table's trailer counts the records it cannot serve -- a child flag that says
     "continue" (tree_eval.cu:101-102 with -1 at the last level: no contribution), a numerator for the IEEE divide -- and one
-    such record sends the whole forest down the general path.  Either way, and with the knob off: the oracle's labels, on a
-    batch that fills the chip (512-thread workgroups) and on a small one."""
+    such record sends the whole forest down the general path; so does, by default, a forest that uses less than half of its
+    deepest level.  With the knob forced on, off and left alone: the oracle's labels, on a batch that fills the chip
+    (512-thread workgroups) and on a small one."""
     synth = rdf.synth
     rng = np.random.default_rng(5 + trees * 100 + levels)
     f_np = synth.forest(trees, levels, classes, topology, 700 + trees)
@@ -991,14 +994,17 @@ def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_o
     slots = trees << levels
     trailer = slots * (48 + 32) + (trees << (levels - 1)) * 64
     assert packed.nbytes == trailer + 64
-    unusable = int(packed.get()[trailer:trailer + 4].view(np.uint32)[0])
+    unusable, in_use = (int(x) for x in packed.get()[trailer:trailer + 8].view(np.uint32))
     assert unusable == (1 if spoil in ("continue_flag", "huge_numerator") else 0)
+    # word 1: the deepest nodes some parent continues to (the default takes the table from half of the level on)
+    to_child = f_np[:, first // 2:first, 5:7].reshape(trees, -1)
+    assert in_use == int(((to_child >= -1) & (to_child < 0)).sum())
     for n, h, w in ((40, 240, 424), (2, 70, 90)):
         frames = synth.frames(["dense", "live"] * (n // 2), 31 + n, h, w)
         want = np.full(frames.shape, 65535, np.uint16)
         oracle.eval_forest(frames, f_np, want)
         depth = rdf.to_device(frames)
-        for knob in (1, 0):
+        for knob in (1, 0, -1):
             lib.rdf_set_last_level_table(knob)
             try:
                 labels = rdf.DeviceArray(frames.shape, np.uint16).fill(65535)
