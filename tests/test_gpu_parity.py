@@ -1012,3 +1012,57 @@ def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_o
                 assert np.array_equal(labels.get(), want), (n, knob, int((labels.get() != want).sum()))
             finally:
                 lib.rdf_set_last_level_table(-1)
+
+
+def test_last_level_table_fuzz(rdf, evs, oracle, gpu_runtime):
+    """Seeded fuzz aimed at the last-level table: forests of one to four classes, two to twelve levels, sides that turn into
+    leaves with probability 0 ... 0.3 per level, few levels pinned in LDS (so level D-1 is walked from the table), now and then
+    a deepest node the table cannot serve; knob forced on / left alone, random launch geometry, reduce, scale, filter,
+    pre-fill -- bit-exact against the C oracle."""
+    rounds = int(os.environ.get("RDF_LAST_LEVEL_FUZZ_ROUNDS", "50"))
+    rng = np.random.default_rng(int(os.environ.get("RDF_FUZZ_SEED", "20211003")) + 29)
+    lib = gpu_runtime.lib
+    synth = rdf.synth
+    try:
+        for it in range(rounds):
+            T, D, C = int(rng.integers(1, 10)), int(rng.integers(2, 13)), int(rng.integers(1, 5))
+            p = float(rng.choice([0.0, 0.0, 0.02, 0.1, 0.3]))
+            forest = np.stack([synth.full_tree(5000 + 10 * it + k, D, C) if p == 0 else
+                               synth.trained_like_tree(5000 + 10 * it + k, D, C, leaf_prob=p, min_leaf_level=int(rng.integers(0, 4)))
+                               for k in range(T)])
+            first = (1 << (D - 1)) - 1
+            forest[:, first:, 7:] = rng.random((T, first + 1, 2 * C), dtype=np.float32)
+            spoil = rng.random()
+            if spoil < 0.1:
+                forest[int(rng.integers(0, T)), first + int(rng.integers(0, first + 1)), 5 + int(rng.integers(0, 2))] = -1.0
+            elif spoil < 0.2:
+                forest[int(rng.integers(0, T)), first + int(rng.integers(0, first + 1)), int(rng.integers(0, 4))] = float(rng.choice([3e7, np.nan, 1e-40]))
+            big = rng.random() < 0.15
+            n, h, w = (int(rng.integers(30, 50)), 240, 424) if big else (int(rng.integers(1, 4)), int(rng.integers(1, 90)), int(rng.integers(1, 200)))
+            r = int(rng.choice([1, 1, 2, 3]))
+            s = float(rng.choice([1.0, 0.5, 1.5]))
+            kinds = [str(k) for k in rng.choice(["dense", "live"], size=n)]
+            depth = synth.frames(kinds, 9000 + it, h, w)
+            depth[rng.random(depth.shape) < 0.02] = 0
+            use_filter = rng.random() < 0.3
+            filt = rng.integers(0, 3, size=(n, h // r, w // r)).astype(np.uint16) if use_filter else None
+            prefill = int(rng.choice([65535, 0]))
+            lib.rdf_set_last_level_table(int(rng.choice([1, 1, -1])))
+            lib.rdf_set_lds_levels(int(rng.integers(0, D)))
+            lib.rdf_set_block_threads(int(rng.choice([0, 256, 512])))
+            lib.rdf_set_halo(int(rng.choice([-1, 0, 16, 40])))
+            lib.rdf_set_group(int(rng.choice([0, 0, 1, 2, 3, 4])))
+            lib.rdf_set_rows_per_wave(int(rng.choice([0, 1, 2, 4])))
+            lib.rdf_set_tree_waves(int(rng.choice([-1, 0])))
+            want = np.full((n, h // r, w // r), prefill, np.uint16)
+            oracle.eval_forest(depth, forest, want, r, filt, 2 if use_filter else None, s)
+            got = _gpu_forest(rdf, evs["packed"], depth, forest, prefill, r, filt, 2 if use_filter else None, s)
+            assert np.array_equal(got, want), f"iteration {it}: T{T} D{D} C{C} p{p} {n}x{h}x{w} r{r} s{s}: {(got != want).sum()} pixels"
+    finally:
+        lib.rdf_set_last_level_table(-1)
+        lib.rdf_set_lds_levels(-1)
+        lib.rdf_set_block_threads(0)
+        lib.rdf_set_halo(-1)
+        lib.rdf_set_group(0)
+        lib.rdf_set_rows_per_wave(0)
+        lib.rdf_set_tree_waves(-1)
