@@ -329,7 +329,10 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
     const int walk_levels = last_from_table ? a.D - 1 : a.D;
     for (uint32_t i = tid; i < (uint32_t)a.T * lds_pitch; i += BLOCK) {
         const uint32_t k = i >> K, h = i & (lds_pitch - 1u);
-        if (h == 0u) continue;
+        if (h == 0u) {      // slot 0: the all-zero node that finished tree slots fetch (see the level loop)
+            if (K > 0) lds_nodes[i] = make_uint4(0u, 0u, 0u, 0u);
+            continue;
+        }
         if (PACKED) {
             lds_nodes[i] = reinterpret_cast<const uint4 *>(a.packed16)[((size_t)k << a.D) + h];
         } else {
@@ -637,10 +640,12 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                         float df_e = df;     // (a copy the mode switches tie)
                         if (!PACKED && fast_levels && j == K) set_round_nearest(df_e);
                         Node n[GROUP];
-                        uint32_t hn[GROUP];   // node to fetch: a finished (negative) or idle slot reads the level's first node (discarded);
-                                              // a walking slot's node is >= 2^j
+                        uint32_t hn[GROUP];   // node to fetch.  A finished (negative) or idle slot reads slot 0 of its tree's table, the
+                                              // all-zero node: offsets 0, so its two (discarded) probes are the pixel itself -- inside
+                                              // the staged tile, never a far load (on the trained-like topology 44 % of the slot-levels
+                                              // are such slots).  The reference layout has no slot 0: there it is the level's first node.
 #pragma unroll
-                        for (int k = 0; k < GROUP; ++k) hn[k] = (uint32_t)max((int)h[k], 1 << j);
+                        for (int k = 0; k < GROUP; ++k) hn[k] = (uint32_t)max((int)h[k], (PACKED || in_lds) ? 0 : 1 << j);
                         if (in_lds) {
 #pragma unroll
                             for (int k = 0; k < GROUP; ++k) {
@@ -769,7 +774,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                 // PDF table, 16-byte rows: ((tree << D) + node) * 2 + side = (tree << (D + 1)) + (h & ~kDone), see add_leaf_pdf
                                 const uint4 *leaf = reinterpret_cast<const uint4 *>(a.packed_pdf) + (((size_t)tk << (a.D + 1)) + (h[k] & ~kDone));
                                 const uint4 *pp = ended ? leaf : rec + 1;
-                                uint4 w = rec[0];
+                                // (a lane that is not walking takes the all-zero node of slot 0: probes inside the tile)
+                                const uint4 *np = walking ? rec : reinterpret_cast<const uint4 *>(a.packed16) + ((size_t)tk << a.D);
+                                uint4 w = np[0];
                                 float4 pa = *reinterpret_cast<const float4 *>(pp);
                                 float4 pb = *reinterpret_cast<const float4 *>(pp + 1);
                                 // (the three loads are issued together -- a record's line is filled once -- and nothing is
