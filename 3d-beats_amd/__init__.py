@@ -14,10 +14,11 @@ from .decision_tree import (DecisionForest, DecisionTree, DecisionTreeEvaluator,
                             DecisionTreeTrainer, LayeredDecisionForest)
 from .device import DeviceArray, HipRuntime, device_ptr, get_runtime, set_runtime, to_device  # noqa: F401
 from .engine.buffer import GpuBuffer  # noqa: F401
+from .host_stream import HostFramesEvaluator  # noqa: F401
 from .pipeline import HandPipeline  # noqa: F401
 from .util import MAX_UINT16  # noqa: F401
 
 __all__ = ["DecisionTree", "DecisionForest", "LayeredDecisionForest", "DecisionTreeEvaluator", "DecisionTreeTrainer",
-           "GpuBuffer", "HandPipeline",
+           "GpuBuffer", "HandPipeline", "HostFramesEvaluator",
            "DeviceArray", "HipRuntime", "MAX_UINT16", "RdfError", "device_ptr", "get_runtime", "set_runtime",
            "to_device", "library_path", "synth"]

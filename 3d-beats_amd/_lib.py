@@ -28,6 +28,8 @@ SIGNATURES = {
     "rdf_forest_pack": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
     "rdf_eval_forest_packed": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
                                         _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
+    "rdf_eval_forest_packed_filled": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
+                                               _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "rdf_eval_forest_stats": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                                        _c_void_p, _c_int, _c_void_p, _c_int, _c_float, _c_void_p, _c_void_p]),
     "rdf_mean_shift_workspace_bytes": (_c_size_t, [_c_int, _c_int]),

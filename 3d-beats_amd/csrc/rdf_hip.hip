@@ -1705,6 +1705,22 @@ int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_
                        stream);
 }
 
+int rdf_eval_forest_packed_filled(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
+                                  const float *forest, int n_trees, int max_depth, int n_classes,
+                                  const uint16_t *filter, int filter_class, uint16_t *labels_out,
+                                  int labels_reduce, void *stream)
+{
+    if (max_depth > 27) return RDF_ERR_BAD_ARG;
+    if (!packed) {      // degenerate forest (no tree or depth 0): nothing is evaluated, every label pixel is 65535
+        if (n_trees > 0 && max_depth > 0) return RDF_ERR_NULL_PTR;
+        if (n_img < 0 || dim_x < 0 || dim_y < 0 || labels_reduce < 1) return RDF_ERR_BAD_ARG;
+        const size_t n = (size_t)n_img * (size_t)(dim_x / labels_reduce) * (size_t)(dim_y / labels_reduce);
+        return rdf_fill_u16(labels_out, n, (uint16_t)kNoPixel, stream);
+    }
+    return eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees, max_depth, n_classes, filter, filter_class,
+                       labels_out, labels_reduce, 1.0f, 0, nullptr, stream, /*fill_untouched=*/1);
+}
+
 int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, int dim_y, const int32_t *cond,
                   int n_cond, uint16_t *out, int32_t *bad_count, void *stream)
 {

@@ -291,6 +291,19 @@ class DecisionTreeEvaluator:
     # -- forest: evaluate_image_using_forest ---------------------------------------------------
     def get_labels_forest(self, forest, depth_images_in, labels_out, labels_reduce=1, filter_images=None,
                           filter_images_class=None, scale_factor=1.):
+        self._forest_call(forest, depth_images_in, labels_out, labels_reduce, filter_images, filter_images_class,
+                          scale_factor, False)
+
+    def get_labels_forest_filled(self, forest, depth_images_in, labels_out, labels_reduce=1, filter_images=None,
+                                 filter_images_class=None, scale_factor=1.):
+        """get_labels_forest with the caller's `labels_out.fill(MAX_UINT16)` folded into the same pass: every label pixel the
+        evaluation leaves alone (no depth, filtered out) is written 65535.  Not in the reference, whose callers fill first
+        (decision_tree.py:237-240)."""
+        self._forest_call(forest, depth_images_in, labels_out, labels_reduce, filter_images, filter_images_class,
+                          scale_factor, True)
+
+    def _forest_call(self, forest, depth_images_in, labels_out, labels_reduce, filter_images, filter_images_class,
+                     scale_factor, fill_untouched):
         num_images, dim_y, dim_x = depth_images_in.shape
 
         assert tuple(labels_out.shape) == (num_images, dim_y // labels_reduce, dim_x // labels_reduce)
@@ -310,11 +323,14 @@ class DecisionTreeEvaluator:
             o = _at(labels_out, i0, lpix * 2)
             f = _at(filter_images, i0, lpix * 2) if filter_images is not None else None
             if packed is not None:
-                rc = lib.rdf_eval_forest_packed(d, n, dim_x, dim_y, packed.ptr, device_ptr(forest.forest_cu),
-                                                int(forest.num_trees), int(forest.max_depth), int(forest.num_classes),
-                                                f, filter_class, o, int(labels_reduce), st)
+                fn = lib.rdf_eval_forest_packed_filled if fill_untouched else lib.rdf_eval_forest_packed
+                rc = fn(d, n, dim_x, dim_y, packed.ptr, device_ptr(forest.forest_cu),
+                        int(forest.num_trees), int(forest.max_depth), int(forest.num_classes),
+                        f, filter_class, o, int(labels_reduce), st)
                 _lib.check(lib, rc, "rdf_eval_forest_packed")
             else:
+                if fill_untouched:      # (the reference-layout entry point has no fused fill)
+                    _lib.check(lib, lib.rdf_fill_u16(o, n * lpix, 65535, st), "rdf_fill_u16")
                 rc = lib.rdf_eval_forest(d, n, dim_x, dim_y, device_ptr(forest.forest_cu),
                                          int(forest.num_trees), int(forest.max_depth), int(forest.num_classes),
                                          f, filter_class, o, int(labels_reduce), float(scale_factor), st)

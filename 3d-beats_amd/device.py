@@ -117,6 +117,31 @@ class _Storage:
         self.version = 0
 
 
+class _HostMappedStorage:
+    """Pinned host memory that kernels can read and write (alloc_host_mapped) behind the same interface."""
+    __slots__ = ("handle", "nbytes", "version", "rt", "host_view")
+
+    def __init__(self, rt, nbytes):
+        got = rt.alloc_host_mapped(nbytes)
+        if got is None:
+            raise _lib.RdfError("pinned, device-mapped host memory is not available")
+        self.rt = rt
+        self.handle, _, self.host_view = got
+        self.nbytes = nbytes
+        self.version = 0
+
+
+def host_mapped_array(shape, dtype):
+    """(DeviceArray, numpy array) over the SAME pinned host memory: kernels write it through the DeviceArray's pointer (the
+    stores cross PCIe), the host reads the numpy array once the writing stream has been waited for."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(x) for x in (shape if not isinstance(shape, (int, np.integer)) else (shape,)))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    st = _HostMappedStorage(get_runtime(), max(nbytes, 1))
+    arr = DeviceArray(shape, dtype, _storage=st)
+    return arr, st.host_view[:nbytes].view(dtype).reshape(shape)
+
+
 class DeviceArray:
     """C-contiguous n-d array in device memory (the GPUArray subset the RDF path needs)."""
 

@@ -137,6 +137,15 @@ int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_
                            const uint16_t *filter, int filter_class,
                            uint16_t *labels_out, int labels_reduce, void *stream);
 
+/* The same with the caller's pre-fill folded in: every label pixel the evaluation leaves alone (no depth, filtered out)
+ * is written 65535, so labels_out needs no fill before the call (the fills of src/decision_tree.py:237-240 and the
+ * `labels.fill(MAX_UINT16)` every caller of get_labels_forest does first).  One pass over the labels instead of two. */
+int rdf_eval_forest_packed_filled(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                                  const void *packed, const float *forest,
+                                  int n_trees, int max_depth, int n_classes,
+                                  const uint16_t *filter, int filter_class,
+                                  uint16_t *labels_out, int labels_reduce, void *stream);
+
 /*
  * Visit counters for the roofline figure: same walk as rdf_eval_forest, labels_out
  * written identically; stats (device uint64[3]) += {evaluated label-pixels, node records read,

@@ -49,6 +49,10 @@ class _OracleLib:
         rc = self._o.rdf_oracle_eval_forest(depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, None, 0)
         return 0 if rc == 0 else -1
 
+    def rdf_eval_forest_packed_filled(self, depth, n_img, dim_x, dim_y, packed, forest, T, D, C, filt, fcls, out, r, stream):
+        self.rdf_fill_u16(out, int(n_img) * (int(dim_y) // int(r)) * (int(dim_x) // int(r)), 65535, stream)
+        return self.rdf_eval_forest_packed(depth, n_img, dim_x, dim_y, packed, forest, T, D, C, filt, fcls, out, r, stream)
+
     def rdf_composite(self, images, n_images, dim_x, dim_y, cond, n_cond, out, bad, stream):
         self.calls.append(("rdf_composite", n_images, dim_x, dim_y, n_cond))
         nb = ctypes.c_int64(0)

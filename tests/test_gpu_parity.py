@@ -1066,3 +1066,32 @@ def test_last_level_table_fuzz(rdf, evs, oracle, gpu_runtime):
         lib.rdf_set_group(0)
         lib.rdf_set_rows_per_wave(0)
         lib.rdf_set_tree_waves(-1)
+
+
+@pytest.mark.parametrize("path", ["packed", "direct"])
+def test_filled_entry_point_equals_fill_then_evaluate(path, rdf, evs, oracle, gpu_runtime):
+    """rdf_eval_forest_packed_filled / get_labels_forest_filled: the caller's 65535 fill folded into the evaluation, on big and
+    small launches, with and without a filter, at labels_reduce 1 and 2, from a label buffer full of something else."""
+    synth = rdf.synth
+    f_np = synth.forest(4, 9, 4, "trained", 310)
+    forest = rdf.DecisionForest.from_numpy(f_np)
+    rng = np.random.default_rng(3)
+    for n, h, w in ((40, 240, 424), (2, 70, 90)):
+        frames = synth.frames(["dense", "live"] * (n // 2), 77 + n, h, w)
+        frames[rng.random(frames.shape) < 0.05] = 0
+        depth = rdf.to_device(frames)
+        for r in (1, 2):
+            for use_filter in (False, True):
+                filt = rng.integers(0, 3, size=(n, h // r, w // r)).astype(np.uint16) if use_filter else None
+                want = np.full((n, h // r, w // r), 65535, np.uint16)
+                oracle.eval_forest(frames, f_np, want, r, filt, 2 if use_filter else None)
+                labels = rdf.DeviceArray(want.shape, np.uint16).fill(4242)
+                evs[path].get_labels_forest_filled(forest, depth, labels, r, rdf.to_device(filt) if use_filter else None,
+                                                   2 if use_filter else None)
+                assert np.array_equal(labels.get(), want), (n, r, use_filter, int((labels.get() != want).sum()))
+    # a degenerate forest (depth 0): nothing to evaluate, every pixel 65535
+    lib = gpu_runtime.lib
+    labels = rdf.DeviceArray((2, 70, 90), np.uint16).fill(7)
+    assert lib.rdf_eval_forest_packed_filled(rdf.to_device(frames).ptr, 2, 90, 70, None, None, 0, 0, 4, None, -1, labels.ptr, 1,
+                                             gpu_runtime.stream()) == 0
+    assert np.all(labels.get() == 65535)

@@ -262,3 +262,21 @@ def test_config1_single_frame_plumbing_on_cpu(rdf, host_runtime, oracle, oracle_
     out = rdf.DeviceArray((1, 480, 848), np.uint16).fill(65535)
     ev.get_labels(tree, rdf.to_device(frame), out)
     assert np.array_equal(out.get(), want)
+
+
+def test_filled_variant_needs_no_fill_first(rdf, host_runtime):
+    """get_labels_forest_filled = the caller's fill of decision_tree.py:237-240 + get_labels_forest, whatever the label
+    buffer held before; the reference-named method keeps the reference's signature and leaves untouched pixels alone."""
+    g = np.load(GOLDEN)
+    forest = rdf.DecisionForest.from_numpy(g["g1_forest"])
+    depth = rdf.to_device(g["g1_depth"])
+    for use_packed in (True, False):
+        ev = rdf.DecisionTreeEvaluator(use_packed=use_packed)
+        labels = rdf.DeviceArray(g["g1_labels"].shape, np.uint16).fill(1234)
+        ev.get_labels_forest_filled(forest, depth, labels)
+        assert np.array_equal(labels.get(), g["g1_labels"])
+        plain = rdf.DeviceArray(g["g1_labels"].shape, np.uint16).fill(1234)
+        ev.get_labels_forest(forest, depth, plain)
+        untouched = g["g1_labels"] == 65535
+        assert untouched.any() and np.all(plain.get()[untouched] == 1234)
+        assert np.array_equal(plain.get()[~untouched], g["g1_labels"][~untouched])

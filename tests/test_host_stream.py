@@ -1,0 +1,68 @@
+"""HostFramesEvaluator: frames in pinned host memory in, labels in pinned host memory out, as a pipeline over two slots --
+the labels written to the host by the kernel itself (the default) or downloaded by a copy engine.
+The reference's counterpart is the per-frame upload / evaluate / read back of run_live_layered.py:66-81; every step's labels
+must be the oracle's for THAT step's frames, whatever is in flight around it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("copy_engine", [False, True])
+@pytest.mark.parametrize("pieces,reduce", [(2, 1), (1, 1), (3, 2), (8, 1)])
+def test_every_step_gets_its_own_frames_labels(pieces, reduce, copy_engine, rdf, gpu_runtime, oracle):
+    synth = rdf.synth
+    n, h, w = 6, 96, 168
+    f_np = synth.forest(4, 9, 4, "trained", 80)
+    forest = rdf.DecisionForest.from_numpy(f_np)
+    p = rdf.HostFramesEvaluator(forest, (n, h, w), labels_reduce=reduce, pieces=pieces, labels_by_copy_engine=copy_engine)
+    assert p.next_frames().shape == (n, h, w) and p.labels_shape == (n, h // reduce, w // reduce)
+    steps = 7
+    batches = [synth.frames(["dense", "live"] * (n // 2), 500 + 10 * s, h, w) for s in range(steps)]
+    for b in batches:
+        b[:, :3, :5] = 0                      # pixels without depth stay 65535 in every step (the slot is refilled)
+    want = []
+    for b in batches:
+        x = np.full(p.labels_shape, 65535, np.uint16)
+        oracle.eval_forest(b, f_np, x, reduce)
+        want.append(x)
+    tickets, got = [], {}
+    for s in range(steps):
+        p.next_frames()[:] = batches[s]
+        tickets.append(p.submit())
+        if s >= 1:                            # read one step behind: two steps are in flight
+            got[s - 1] = p.result(tickets[s - 1]).copy()
+    got[steps - 1] = p.result(tickets[-1]).copy()
+    p.drain()
+    for s in range(steps):
+        assert np.array_equal(got[s], want[s]), (s, int((got[s] != want[s]).sum()))
+    # a ticket whose slot has been reused is refused, not answered with another step's labels
+    with pytest.raises(ValueError):
+        p.result(tickets[0])
+    with pytest.raises(ValueError):
+        p.result(steps)
+
+
+def test_next_frames_waits_for_the_slots_upload(rdf, gpu_runtime, oracle):
+    """Overwriting a host slot right after its step was submitted must not change that step's labels: next_frames() hands
+    the slot out again only when its upload has left."""
+    synth = rdf.synth
+    n, h, w = 4, 120, 200
+    f_np = synth.forest(3, 8, 4, "full", 90)
+    forest = rdf.DecisionForest.from_numpy(f_np)
+    p = rdf.HostFramesEvaluator(forest, (n, h, w))
+    a, b, c = (synth.frames(["dense"] * n, 900 + k, h, w) for k in range(3))
+    p.next_frames()[:] = a
+    t0 = p.submit()
+    p.next_frames()[:] = b
+    t1 = p.submit()
+    buf = p.next_frames()                     # slot of step 0 again: blocks until step 0's frames are on the device
+    buf[:] = c
+    got0 = p.result(t0).copy()
+    t2 = p.submit()
+    want = [np.full((n, h, w), 65535, np.uint16) for _ in range(3)]
+    for x, fr in zip(want, (a, b, c)):
+        oracle.eval_forest(fr, f_np, x)
+    assert np.array_equal(got0, want[0])
+    assert np.array_equal(p.result(t1), want[1])
+    assert np.array_equal(p.result(t2), want[2])
