@@ -360,10 +360,12 @@ class PeerCopyGather:
         _lib.check(self._lib, self._lib.rdf_stream_synchronize(st), "rdf_stream_synchronize")
 
     def own_slot(self, step, shape, dtype=np.uint16):
-        """Rank dst: its OWN place in the ring for `step` as a DeviceArray, so that it evaluates straight into the ring
-        instead of copying 100 MB inside one device -- such a copy is a shader blit, not a copy-engine transfer, and takes
-        CUs from the forest kernel (104 MB during a launch: 3.2 ms, the launch 4.40 instead of 4.04 ms on the test box)."""
-        assert self.rank == self.dst and self._owned is not None
+        """This rank's place in the ring for `step` as a DeviceArray.  Rank dst evaluates straight into it instead of copying
+        100 MB inside one device -- such a copy is a shader blit, not a copy-engine transfer, and takes CUs from the forest
+        kernel (104 MB during a launch: 3.2 ms, the launch 4.40 instead of 4.04 ms on the test box).  On any other rank the
+        array is rank dst's memory seen through the IPC mapping: a kernel that writes it stores across xGMI
+        (PeerCopyForestEvaluator(direct_stores=True))."""
+        assert self.base is not None and (self.rank == self.dst) == (self._owned is not None)
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         assert nbytes == self.bytes_per_rank
         st = _Storage.__new__(_Storage)
@@ -391,11 +393,13 @@ class PeerCopyGather:
 
 class PeerCopyForestEvaluator:
     """One launch per step; each rank copies its label maps into rank `dst`'s ring on a side stream, so the copy
-    of step s overlaps the launch of step s+1 (two label buffers used alternately, as in step_overlapped).  With
+    of step s overlaps the launch of step s+1 (two label buffers used alternately, as in step_overlapped) -- or, with
+    direct_stores, writes them there from the kernel itself.  With
     flow_control the producer waits (host side, before it reuses a ring slot) until the consumer on rank dst has released
     the step that used the slot before: PeerCopyGather.wait_ready / slot_array / release are the consumer's side."""
 
-    def __init__(self, evaluator, forest, frames_per_rank, depth_dims, gather, labels_reduce=1, scale_factor=1., flow_control=False):
+    def __init__(self, evaluator, forest, frames_per_rank, depth_dims, gather, labels_reduce=1, scale_factor=1., flow_control=False,
+                 direct_stores=False):
         import torch
         self.torch = torch
         self.ev, self.forest, self.gather = evaluator, forest, gather
@@ -407,6 +411,11 @@ class PeerCopyForestEvaluator:
         self._lib = get_runtime().lib
         self.copy_stream = torch.cuda.Stream()
         self.flow_control = bool(flow_control)
+        # direct_stores: EVERY rank evaluates straight into its place in rank dst's ring -- the kernel's label stores cross
+        # xGMI (a wave's 64 labels are one 128-byte store; 104 MB per 3.9-ms step = 27 GB/s per rank, one link each into
+        # rank dst), there is no copy and no second label buffer.  The same thing with pinned host memory as the target
+        # costs the kernel nothing (HostFramesEvaluator, profiles/r03_pcie_overlap.txt); across GPUs it has never run.
+        self.direct_stores = bool(direct_stores)
         self._copied = {}
         self._own = {}            # (rank dst) DeviceArrays over its own places in the ring
         self.last_labels = None
@@ -420,9 +429,9 @@ class PeerCopyForestEvaluator:
         torch = self.torch
         g = self.gather
         cur = torch.cuda.current_stream()
-        if g.rank == g.dst:
-            # rank dst evaluates straight into its place in the ring (no copy inside one device); with flow control it
-            # waits for the slot BEFORE the launch, not before a copy
+        if g.rank == g.dst or self.direct_stores:
+            # rank dst (with direct_stores: every rank) evaluates straight into its place in the ring (no copy); with flow
+            # control it waits for the slot BEFORE the launch, not before a copy
             if self.flow_control and not g.wait_free(self._step_no):
                 raise _lib.RdfError(f"rank {g.rank}: the consumer never released the ring slot of step {self._step_no}")
             key = self._step_no % g.n_slots

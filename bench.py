@@ -80,7 +80,8 @@ def parse():
                     help="how the label maps reach rank 0 at N>1: p2p = every rank copies its shard into rank 0's "
                          "IPC-mapped ring with the copy engines (no CU involved); rccl = torch.distributed.gather on a "
                          "compute stream that leaves 32 CUs to RCCL; "
-                         "auto (default) = time both back to back, `value` is the faster one's and `gather_modes` carries both "
+                         "auto (default) = time those two and `p2p direct stores` (every rank's kernel writes its labels straight "
+                         "into rank 0's ring, no copy) back to back, `value` is the fastest intact one's and `gather_modes` carries all "
                          "(rccl alone if the buffer cannot be mapped); both = the same, but `value` is p2p's")
     ap.add_argument("--reserve-cus", type=int, default=-1, help="run the forest kernel on a stream that leaves this many CUs "
                     "(one per shader engine = 32) to RCCL's kernels; -1: 32 with the rccl gather, 0 otherwise (DESIGN.md section 6)")
@@ -409,13 +410,21 @@ def main():
 
     # N>1, default: peer copies over xGMI by the copy engines (RCCL carries only the control plane); needs HIP IPC
     # between the ranks' processes, falls back to the RCCL gather if any rank cannot map rank 0's buffer
-    peer, pg, notes = None, None, {}      # notes: what was unavailable on this run and why (goes on the N > 1 line)
+    peer, pg, peer_direct, pg_d, notes = None, None, None, None, {}      # notes: what was unavailable on this run and why (goes on the N > 1 line)
     if world > 1 and a.chunks == 0 and a.gather in ("auto", "p2p", "both"):
         pg = dmod.PeerCopyGather(world, rank, F * H * W * 2, _fail_open_on_rank=a.fail_ipc_open_on_rank)
         if pg.ok:
             peer = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg)
         else:
             notes["p2p"] = "unavailable: " + "; ".join(f"rank {g}: {why}" for g, why in (pg.errors or {}).items())
+        # the same ring a second time for the mode in which every rank's kernel writes its labels straight into rank 0's
+        # memory (no copy at all): its own ring, so that the two modes' step counters do not meet
+        if pg.ok and a.gather in ("auto", "both"):
+            pg_d = dmod.PeerCopyGather(world, rank, F * H * W * 2)
+            if pg_d.ok:
+                peer_direct = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg_d, direct_stores=True)
+            else:
+                notes["p2p direct stores"] = "unavailable: " + "; ".join(f"rank {g}: {why}" for g, why in (pg_d.errors or {}).items())
 
     # ---- algorithmic bytes of one step, from the visit counters of the same walk ----
     dstats = rdf.DeviceArray((3,), np.uint64).fill(0)
@@ -523,6 +532,8 @@ def main():
     else:
         if peer is not None and a.gather != "rccl":
             modes["p2p copy engines"] = (lambda: peer.step(depth, ring), peer.drain, None, 0, peer.result, True)
+        if peer_direct is not None:
+            modes["p2p direct stores"] = (lambda: peer_direct.step(depth, None), peer_direct.drain, None, 0, peer_direct.result, True)
         if "p2p copy engines" not in modes or a.gather in ("rccl", "both", "auto"):
             modes["rccl gather"] = rccl_mode()
     torch.cuda.synchronize()
@@ -547,13 +558,14 @@ def main():
                 queue.append(("rccl gather", modes["rccl gather"]))
             continue
         results[name] = {"elapsed": elapsed, "kern_ms": kms, "reserve": reserve, "gather_check": check}
-        if name == "p2p copy engines" and rank == 0:
+        if name in ("p2p copy engines", "p2p direct stores") and rank == 0:
             # the ring's ready counters after the drain: the last two steps of every rank are marked as landed
             try:
-                last = peer.steps_done - 1
-                cnt = pg.ready_counters()
-                results[name]["ready_counters_ok"] = bool((cnt[last % pg.n_slots] == last + 1).all() and
-                                                          (pg.n_slots < 2 or last < 1 or (cnt[(last - 1) % pg.n_slots] == last).all()))
+                pe_, pg_ = (peer, pg) if name == "p2p copy engines" else (peer_direct, pg_d)
+                last = pe_.steps_done - 1
+                cnt = pg_.ready_counters()
+                results[name]["ready_counters_ok"] = bool((cnt[last % pg_.n_slots] == last + 1).all() and
+                                                          (pg_.n_slots < 2 or last < 1 or (cnt[(last - 1) % pg_.n_slots] == last).all()))
             except Exception as e:   # noqa: BLE001
                 results[name]["ready_counters_ok"] = f"not read: {e}"[:120]
     if not results:
@@ -562,7 +574,12 @@ def main():
     # seen either mode cross two GPUs before the driver's run, so the default times both (K steps each) and says so
     primary = next(iter(results))
     if a.gather == "auto" and len(results) > 1:
-        primary = min(results, key=lambda n: results[n]["elapsed"])       # (`elapsed` is the MAX over ranks: same on every rank)
+        # (`elapsed` is the MAX over ranks and the check's verdict is broadcast below: the same choice on every rank; a mode
+        # whose label maps did not arrive intact is never `value`)
+        verdicts = [{n: r["gather_check"] for n, r in results.items()}]
+        dist.broadcast_object_list(verdicts, src=0)
+        intact = [n for n in results if verdicts[0].get(n) == "ok"] or list(results)
+        primary = min(intact, key=lambda n: results[n]["elapsed"])
     elapsed, kern_ms = results[primary]["elapsed"], results[primary]["kern_ms"]
     if world == 1:
         assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"

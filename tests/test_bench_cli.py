@@ -35,7 +35,9 @@ def test_single_gpu_line_has_roofline_and_legs(tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "Mpix/s" and d["value"] > 0
     assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"]
     # `value` is the median of the per-step times, the K steps between the barriers are beside it
-    assert d["value_is"].startswith("median") and d["value_mean"] > 0 and abs(d["value"] / d["value_mean"] - 1) < 0.2
+    # (three steps of a tiny batch: the bracketed wall time is mostly barriers and launch overhead, so the mean rate is only
+    # required to exist and not to beat the median by much)
+    assert d["value_is"].startswith("median") and d["value_mean"] > 0 and d["value"] > 0.4 * d["value_mean"]
     assert abs(d["ms_per_step"] * d["value"] - 8 * 480 * 848 / 1e3) < 1e-2 * d["ms_per_step"] * d["value"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "levels", "algorithmic"} <= set(d["roofline"])
     assert d["roofline"]["algorithmic"]["bytes_per_launch"] > 0
@@ -64,10 +66,13 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
     else:
         best = max(dd["gather_modes"], key=lambda n: dd["gather_modes"][n]["value"])
         assert d["config"]["gather"] == best and d["value"] == dd["gather_modes"][best]["value"]
-    assert len(dd["gather_modes"]) == (2 if gather in ("both", "auto") else 1)
+    # both / auto: copy engines, the kernels' own stores into rank 0's ring, and the RCCL gather
+    assert len(dd["gather_modes"]) == (3 if gather in ("both", "auto") else 1)
     assert dd["unavailable"] == {}
     if gather in ("p2p", "both", "auto"):       # the receive ring's ready counters show the last two steps of both ranks
         assert dd["gather_modes"]["p2p copy engines"]["ready_counters_ok"] is True
+    if gather in ("both", "auto"):
+        assert dd["gather_modes"]["p2p direct stores"]["ready_counters_ok"] is True
     # config 5's workload sharded over the same ranks (1280x720 dense frames; the forest shrunk for the test)
     c5 = d["cfg5_all_ranks"]
     assert c5["n_gpus"] == 2 and c5["gather_check"] == "ok" and c5["value"] > 0 and c5["value_kernel_only"] >= c5["value"]
@@ -88,8 +93,9 @@ def test_four_ranks_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 4 and d["config"]["gather_check"] == "ok"
     dd = d["distributed"]
     assert dd["rccl_ranks"] == 4 and len(dd["devices"]) == 4 and sorted(x["rank"] for x in dd["devices"]) == [0, 1, 2, 3]
-    assert all(m["gather_check"] == "ok" for m in dd["gather_modes"].values()) and len(dd["gather_modes"]) == 2
+    assert all(m["gather_check"] == "ok" for m in dd["gather_modes"].values()) and len(dd["gather_modes"]) == 3
     assert dd["unavailable"] == {} and dd["gather_modes"]["p2p copy engines"]["ready_counters_ok"] is True
+    assert dd["gather_modes"]["p2p direct stores"]["ready_counters_ok"] is True
     c5 = d["cfg5_all_ranks"]
     assert c5["n_gpus"] == 4 and c5["gather_check"] == "ok" and "4 x 1 dense" in c5["workload"]
 

@@ -164,9 +164,30 @@ def _p2p_worker(rank, world, port, tmpdir, multi_device=False):
                 gather2.release(s_no)
         pe2.drain()
         torch.cuda.synchronize()
+        dist.barrier()
+
+        # ---- direct stores: every rank's KERNEL writes its label maps into its place in rank 0's ring (no copy, no second
+        # label buffer); same dawdling consumer, same three batches ----
+        gather3 = dmod.PeerCopyGather(world, rank, nbytes, n_slots=2)
+        assert gather3.ok
+        pe3 = dmod.PeerCopyForestEvaluator(ev, forest, frames, (h, w), gather3, labels_reduce=r, scale_factor=0.5, flow_control=True,
+                                           direct_stores=True)
+        for s_no in range(n_steps):
+            out = pe3.step(batches[s_no % 3], None, prefill=65535)
+            assert out.ptr == gather3.slot_ptr(rank, 0, s_no)             # the labels ARE the ring slot, on every rank
+            if rank == 0:
+                time.sleep(0.03)
+                assert gather3.wait_ready(s_no, timeout_s=20.0), s_no
+                got = gather3.slot_array(s_no).cpu().numpy().view(np.uint16).reshape(world * frames, h // r, w // r)
+                for g in range(world):
+                    assert np.array_equal(got[g * frames:(g + 1) * frames], want_for(g, 1000 * (s_no % 3) + g * frames)), ("direct", s_no, g)
+                gather3.release(s_no)
+        pe3.drain()
+        torch.cuda.synchronize()
         if rank == 0:
             open(os.path.join(tmpdir, "ok"), "w").write("ok")
         dist.barrier()
+        gather3.close()
         gather2.close()
         dist.barrier()          # rank 0 is done reading before anyone unmaps
         gather.close()
