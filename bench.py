@@ -763,7 +763,7 @@ def main():
                                                "value_mean": round(F * H * W / step_mean / 1e3, 2),
                                                "ms_per_step_mean": round(step_mean, 3),
                                                "ms_per_step_wall_with_fill_and_drain": round(wall_pp * 1e3, 3),
-                                               "steps": reps,
+                                               "steps": reps, "step_intervals_ms": [round(g, 2) for g in gaps],
                                                "what": "HostFramesEvaluator: frames from pinned host memory, uploaded by a copy engine "
                                                        "while the batch before is evaluated; labels written into pinned host memory by "
                                                        "the kernel itself"}
