@@ -11,9 +11,10 @@ batch of 128 frames of 848x480 (104 MB each way over PCIe gen 5), 48 % of the HB
     with its labels in host memory as in HBM (the stores are posted and 27 GB/s is half of what the link takes), so
     there is no download stage at all -- and the link carries frames up and labels down at the same time, which two copy
     engine transfers did not (H2D next to D2H took the sum of both, 3.7 ms: tools/pcie_overlap_probe.py).
-Measured: 3.93 ms per step, every step (13.2 Gpix/s, the HBM-resident rate); with the labels downloaded by a copy engine
-(`labels_by_copy_engine=True`, two more device slots and a third stream) the median step is 4.06 ms but one step in four
-stalls behind the other direction's transfer (mean 4.8 ms).
+Measured (tools/pcie_overlap_probe.py --host-labels, profiles/r03_pcie_overlap.txt): 3.93-3.97 ms per step, every step
+(13.2 Gpix/s, the HBM-resident rate); with the labels downloaded by a copy engine (`labels_by_copy_engine=True`, two more
+device slots and a third stream) the best split (two pieces) has a median step of 4.1-4.2 ms but steps stall behind the other
+direction's transfer (mean 4.8-5.3 ms, worst 9.6).
 
 Everything is enqueued without blocking the host; `result()` waits for one step's labels.
 

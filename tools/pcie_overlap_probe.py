@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What overlaps with what on this box: pinned H2D of the bench batch's frames, D2H of its labels and the forest kernel, alone
 and in pairs on separate streams (wall time per repetition, 5 repetitions after a warm-up).
-usage: tools/pcie_overlap_probe.py [--frames 128] | --pipelines"""
+usage: tools/pcie_overlap_probe.py [--frames 128] | --pipelines | --host-labels"""
 import argparse
 import os
 import sys
@@ -70,10 +70,6 @@ def main():
     print(f"H2D {mb / t_up / 1e3:.1f} GB/s, D2H {mb / t_dn / 1e3:.1f} GB/s, kernel {t_k * 1e3:.2f} ms")
 
 
-if __name__ == "__main__" and "--pipelines" not in sys.argv:
-    main()
-
-
 def pipelines():
     """Two pipelines over the same work: (i) bench.py's round-3 leg -- four chunks, one device buffer, upload / evaluate / download
     of neighbouring chunks overlap; (ii) whole batches, two device buffers each way: upload of batch r+1, kernel of batch r and
@@ -132,5 +128,57 @@ def pipelines():
         print(f"two device buffers each way, {n_ch} chunk(s) per step: {dt * 1e3:7.3f} ms per step, {F * H * W / dt / 1e6:8.1f} Mpix/s")
 
 
-if __name__ == "__main__" and "--pipelines" in sys.argv:
-    pipelines()
+def host_labels():
+    """The kernel writing its labels straight into pinned, device-mapped host memory: its time next to labels in HBM, and the
+    steady-state step of HostFramesEvaluator both ways (labels by the kernel's own stores / downloaded by a copy engine)."""
+    import torch
+    rdf = import_module("3d-beats_amd")
+    dev = import_module("3d-beats_amd.device")
+    synth = rdf.synth
+    F, H, W = 128, 480, 848
+    frames = synth.frames(["dense", "live"] * (F // 2), 0)
+    forest = rdf.DecisionForest.from_numpy(synth.forest(4, 20, 4, "full"))
+    ev = rdf.DecisionTreeEvaluator(use_packed=True)
+    depth = rdf.to_device(frames)
+    in_hbm = rdf.DeviceArray(frames.shape, np.uint16)
+    in_host, host_view = dev.host_mapped_array(frames.shape, np.uint16)
+
+    def t_kernel(lab, n=6):
+        for i in range(n + 1):
+            if i == 1:
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ev.get_labels_forest_filled(forest, depth, lab)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+    print(f"kernel, labels in HBM      : {t_kernel(in_hbm):.3f} ms")
+    print(f"kernel, labels in host mem : {t_kernel(in_host):.3f} ms   (equal: {np.array_equal(in_hbm.get(), host_view)})")
+    for by_copy, pieces in ((False, 1), (False, 2), (True, 1), (True, 2), (True, 3)):
+        hp = rdf.HostFramesEvaluator(forest, (F, H, W), evaluator=ev, pieces=pieces, labels_by_copy_engine=by_copy)
+        hp.mark_steps = True
+        for b in range(2):
+            hp.frames[b][:] = frames
+        for _ in range(24):
+            hp.next_frames()
+            last = hp.submit()
+        hp.result(last)
+        torch.cuda.synchronize()
+        m = hp.step_marks
+        gaps = [m[i].elapsed_time(m[i + 1]) for i in range(3, len(m) - 1)]
+        print(f"labels {'by a copy engine' if by_copy else 'by the kernel   '}, {pieces} piece(s): median {np.median(gaps):.3f} mean {np.mean(gaps):.3f} "
+              f"max {max(gaps):.2f} ms per step over {len(gaps)} steps")
+        del hp
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    if "--pipelines" in sys.argv:
+        pipelines()
+    elif "--host-labels" in sys.argv:
+        host_labels()
+    else:
+        main()
