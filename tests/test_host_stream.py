@@ -66,3 +66,31 @@ def test_next_frames_waits_for_the_slots_upload(rdf, gpu_runtime, oracle):
     assert np.array_equal(got0, want[0])
     assert np.array_equal(p.result(t1), want[1])
     assert np.array_equal(p.result(t2), want[2])
+
+
+def test_layered_run_writes_its_composite_into_host_memory(rdf, gpu_runtime, oracle):
+    """A result buffer in pinned, device-mapped host memory (GpuBuffer(..., host_mapped=True)): LayeredDecisionForest.run's
+    composite lands in `.host` with no read back, the same image as in a device buffer (both routes of run())."""
+    synth = rdf.synth
+    h, w, r = 240, 424, 2
+    f0, f1 = synth.forest(3, 9, 4, "trained", 60), synth.forest(3, 10, 5, "trained", 70)
+    conditions = [[0, 1], [0, 2], [1, 3], [0, 3], [0, 4], [0, 5], [0, 6], [0, 7]]
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(f0)},
+                      {"model": rdf.DecisionForest.from_numpy(f1), "filter_model": 0, "filter_model_class": 3}],
+           "conditions": conditions, "label_colors": [[10 * i, 0, 0, 255] for i in range(1, 8)]}
+    frame = synth.frames(["live"], 4100, h, w)[0]
+    l0 = np.full((1, h // r, w // r), 65535, np.uint16)
+    l1, comp = l0.copy(), l0.copy()
+    oracle.eval_forest(frame[None], f0, l0, r)
+    oracle.eval_forest(frame[None], f1, l1, r, l0, 3)
+    oracle.composite([l0[0], l1[0]], np.array(conditions, np.int32), comp)
+    dbuf = rdf.GpuBuffer((h, w), np.uint16)
+    dbuf.cu().set(frame)
+    for fused in (True, False):
+        lf = rdf.LayeredDecisionForest(cfg, (h, w), r, fused=fused)
+        out = rdf.GpuBuffer((h // r, w // r), np.uint16, host_mapped=True)
+        assert out.host is not None and out.host.shape == (h // r, w // r)
+        out.host[:] = 7
+        lf.run(dbuf, out, 1.0)
+        gpu_runtime.synchronize()
+        assert np.array_equal(out.host, comp[0]), (fused, int((out.host != comp[0]).sum()))
