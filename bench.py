@@ -714,6 +714,37 @@ def main():
                                    "layers in one forest launch (unfiltered; the composite kernel applies the filter and "
                                    "the reference's three fills are folded in)"}
 
+        # the live loop of run_live_layered.py:66-126 with the frame arriving in (pinned) host memory and the composite wanted
+        # there: upload, run, and the result either read back (the reference's `.get()`) or written to host memory by the
+        # composite kernel itself (GpuBuffer(host_mapped=True)); every frame is waited for, as a live loop does
+        if not a.no_pcie:
+            one_pin = torch.from_numpy(np.array(frames_np[1 if F > 1 else 0]).view(np.int16).reshape(-1)).pin_memory()
+            d1_t = dbuf.cu().torch_bytes().view(torch.int16)
+            hbuf = rdf.GpuBuffer((H // 2, W // 2), np.uint16, host_mapped=True)
+            back = torch.empty((H // 2) * (W // 2), dtype=torch.int16).pin_memory()
+            l1_t = lbuf.cu().torch_bytes().view(torch.int16)
+            live_ms = {}
+            for name in ("read_back", "written_by_the_kernel"):
+                for rep in range(110):
+                    if rep == 10:
+                        torch.cuda.synchronize()
+                        tl = time.perf_counter()
+                    d1_t.copy_(one_pin, non_blocking=True)
+                    if name == "read_back":
+                        lf.run(dbuf, lbuf, 1.0)
+                        back.copy_(l1_t, non_blocking=True)
+                    else:
+                        lf.run(dbuf, hbuf, 1.0)
+                    torch.cuda.synchronize()
+                live_ms[name] = (time.perf_counter() - tl) / 100
+            same3 = bool(np.array_equal(hbuf.host.reshape(-1), back.numpy().view(np.uint16)))
+            out["cfg3_layered_run"].update({
+                "ms_per_frame_wall_from_host_read_back": round(live_ms["read_back"] * 1e3, 4),
+                "ms_per_frame_wall_from_host_composite_written_to_host": round(live_ms["written_by_the_kernel"] * 1e3, 4),
+                "from_host_composites_equal": same3,
+                "from_host_what": "per frame: pinned H2D of the frame, LayeredDecisionForest.run, composite on the host (copied "
+                                  "back / written there by the composite kernel), host waits for every frame"})
+
         # ---- host-buffer variant: pinned H2D of the frames + kernel + D2H of the labels (never `value`) ----
         if not a.no_pcie:
             pin_in = torch.from_numpy(np.array(frames_np).view(np.int16).reshape(-1)).pin_memory()   # (a writable copy: the cache is memory-mapped read-only)
