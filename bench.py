@@ -354,10 +354,47 @@ def main():
                 if not torch.equal(chk, allsums[g]):
                     check = "MISMATCH"
         pix = world * F5 * H5 * W5
+        # the same shard with every rank's kernel writing its labels straight into rank 0's IPC-mapped ring (no transfer stage:
+        # DESIGN.md section 6, third way); collective, and whatever goes wrong on any rank becomes a field
+        direct = None
+        try:
+            pg5 = dmod.PeerCopyGather(world, rank, F5 * H5 * W5 * 2)
+            if pg5.ok:
+                pe5 = dmod.PeerCopyForestEvaluator(ev, forest5, F5, (H5, W5), pg5, direct_stores=True)
+                for _ in range(warmup):
+                    pe5.step(depth5, None)
+                pe5.drain()
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    pe5.step(depth5, None)
+                pe5.drain()
+                sync_all()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                t_direct = float(t.item())
+                chk, got5 = None, None
+                if rank == 0:
+                    chk = "ok"
+                    got5 = pe5.result()
+                    for g in range(world):
+                        p64 = got5[g * F5:(g + 1) * F5].reshape(-1).to(torch.int64)
+                        c2_ = torch.stack([p64.sum(), (p64 * (torch.arange(p64.numel(), device=p64.device) % 8191)).sum()])
+                        if not torch.equal(c2_, allsums[g]):
+                            chk = "MISMATCH"
+                direct = {"value": round(pix * steps / t_direct / 1e6, 2), "ms_per_step": round(t_direct / steps * 1e3, 4),
+                          "gather_check": chk}
+                dist.barrier()
+                pg5.close()
+                del pe5, got5
+            else:
+                direct = {"unavailable": "; ".join(f"rank {g}: {why}" for g, why in (pg5.errors or {}).items())}
+        except Exception as e:   # noqa: BLE001
+            direct = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:300]}
         res = {"value": round(pix * steps / t_gather / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(t_gather / steps * 1e3, 4),
                "value_kernel_only": round(pix * steps / t_kernel / 1e6, 2), "kernel_only_ms": round(t_kernel / steps * 1e3, 4),
                "n_gpus": world, "steps": steps, "warmup": warmup, "gather": "rccl gather to rank 0 inside the timed region",
-               "gather_check": check, "scaling": "weak",
+               "gather_check": check, "scaling": "weak", "p2p_direct_stores": direct,
                "workload": f"{world} x {F5} dense {W5}x{H5} frames, T{T5}/D{D5}/C{C5} full forest replicated "
                            f"(config 5{' itself' if world * F5 == 256 else ' shards'}), {world} GPUs"}
         del forest5, depth5, lab5, slabs

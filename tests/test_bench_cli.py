@@ -76,6 +76,8 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
     # config 5's workload sharded over the same ranks (1280x720 dense frames; the forest shrunk for the test)
     c5 = d["cfg5_all_ranks"]
     assert c5["n_gpus"] == 2 and c5["gather_check"] == "ok" and c5["value"] > 0 and c5["value_kernel_only"] >= c5["value"]
+    # ... and once more with every rank's kernel writing straight into rank 0's ring
+    assert c5["p2p_direct_stores"]["gather_check"] == "ok" and c5["p2p_direct_stores"]["value"] > 0
 
 
 @pytest.mark.gpu
@@ -98,6 +100,7 @@ def test_four_ranks_on_one_gpu(tmp_path):
     assert dd["gather_modes"]["p2p direct stores"]["ready_counters_ok"] is True
     c5 = d["cfg5_all_ranks"]
     assert c5["n_gpus"] == 4 and c5["gather_check"] == "ok" and "4 x 1 dense" in c5["workload"]
+    assert c5["p2p_direct_stores"]["gather_check"] == "ok"
 
 
 @pytest.mark.gpu
