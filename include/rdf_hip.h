@@ -25,6 +25,8 @@
 extern "C" {
 #endif
 
+/* 2: rdf_forest_packed_bytes grew (last-level table behind the three per-slot tables: re-pack with this library's
+ * rdf_forest_pack); new: rdf_set_last_level_table, rdf_eval_forest_packed_filled.  Nothing was removed or re-typed. */
 #define RDF_ABI_VERSION 2
 
 #define RDF_OK 0
