@@ -413,7 +413,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 
         // ---- empty tile?  (live frames are mostly background.)  Every wave looks at the centre depths of its
         // own rows straight from global memory; a tile without a single pixel to evaluate is not staged.
-        // Throughput shape only (a.check_empty): for a single small frame the extra round trip costs more than it saves ----
+        // (a.check_empty: launches that fill the chip, and small ones at labels_reduce > 1 -- eval_common) ----
         if (a.check_empty && tw > 0) {
             bool mine = false;
             for (int sub = 0; sub < rows_per_wave; ++sub) {
@@ -1477,7 +1477,10 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // rows per wave so that every CU still gets several waves.
     const long long waves_wanted = 24ll * di.cus;
     const bool big = (long long)n_img * a.tiles_x * ((a.Hl + kMaxRowsPerWave - 1) / kMaxRowsPerWave) >= waves_wanted;
-    a.check_empty = big ? 1 : 0;
+    // the empty-tile check (see the kernel): always on launches that fill the chip; on small launches only at labels_reduce > 1,
+    // where a staged tile covers r x r times the image per label pixel and a live frame is mostly background (config 3's
+    // two-layer frame 30.5 -> 29.2 us; a dense full-resolution frame gains nothing from it, a trained-like one loses 1 %)
+    a.check_empty = (big || r > 1) ? 1 : env_int("RDF_CHECK_EMPTY_SMALL", 0);
     // Workgroup size.  Big unfiltered launches: 512 threads, three workgroups per CU = 24 waves with a 48-pixel halo
     // (54 KB of LDS each) instead of five 256-thread workgroups = 20 waves with 32 pixels: 4.77 vs 5.14 ms on the bench
     // batch, 11.45 vs 12.60 ms on config 5's shard (profiles/r02_sweep_512.txt).  Small launches keep 256 threads.
