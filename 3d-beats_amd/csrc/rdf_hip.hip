@@ -1479,7 +1479,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     const bool big = (long long)n_img * a.tiles_x * ((a.Hl + kMaxRowsPerWave - 1) / kMaxRowsPerWave) >= waves_wanted;
     // the empty-tile check (see the kernel): always on launches that fill the chip; on small launches only at labels_reduce > 1,
     // where a staged tile covers r x r times the image per label pixel and a live frame is mostly background (config 3's
-    // two-layer frame 30.5 -> 29.2 us; a dense full-resolution frame gains nothing from it, a trained-like one loses 1 %)
+    // two-layer frame 30.5 -> 29.2 us; at labels_reduce 1 the extra round trip costs more than the skipped staging saves:
+    // one live 848x480 frame 41.6 -> 43.5 us, a dense one 76 -> 77 us, tools/latency.py with RDF_CHECK_EMPTY_SMALL=1)
     a.check_empty = (big || r > 1) ? 1 : env_int("RDF_CHECK_EMPTY_SMALL", 0);
     // Workgroup size.  Big unfiltered launches: 512 threads, three workgroups per CU = 24 waves with a 48-pixel halo
     // (54 KB of LDS each) instead of five 256-thread workgroups = 20 waves with 32 pixels: 4.77 vs 5.14 ms on the bench
