@@ -960,12 +960,13 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        if pg is not None and pg.ok:            # unmap on the peers before rank 0 frees the buffer
-            if rank != 0:
-                pg.close()
-            dist.barrier()
-            if rank == 0:
-                pg.close()
+        for ring in (pg, pg_d):                 # unmap on the peers before rank 0 frees the buffer
+            if ring is not None and ring.ok:        # (`ok` is agreed on every rank: the barrier below is entered by all or none)
+                if rank != 0:
+                    ring.close()
+                dist.barrier()
+                if rank == 0:
+                    ring.close()
         for h in handles:
             if h is not None:
                 lib.rdf_stream_destroy(h)
