@@ -26,6 +26,9 @@ SIGNATURES = {
                                       _c_int, _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "rdf_forest_packed_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "rdf_forest_pack": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "rdf_forest_set_deep_from": (_c_int, [_c_void_p, _c_int]),
+    "rdf_forest_tune": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int,
+                                 _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_eval_forest_packed": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
                                         _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "rdf_eval_forest_packed_filled": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
@@ -95,6 +98,7 @@ SIGNATURES = {
     "rdf_set_rows_per_wave": (None, [_c_int]),
     "rdf_set_force_exact": (None, [_c_int]),
     "rdf_set_last_level_table": (None, [_c_int]),
+    "rdf_set_deep_from": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),
     "rdf_event_record": (_c_int, [_c_void_p, _c_void_p]),
     "rdf_event_synchronize": (_c_int, [_c_void_p]),
@@ -105,7 +109,7 @@ SIGNATURES = {
     "rdf_error_string": (ctypes.c_char_p, [_c_int]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -51,6 +51,13 @@
 #include "../../include/rdf_hip.h"
 #include "rdf_device.hpp"
 
+// Trees that walk their deep blocks side by side (k_eval_forest<..., DEEP>).  One: the walk is bound by the L1's line
+// accesses (seven per block and lane), not by the lines in flight -- two trees side by side need 56 registers of block
+// and ran 9.5 against 7.8 ms (spills), 8.4 ms when bounded to four waves per SIMD (profiles/r04_deep_variants.txt).
+#ifndef RDF_DEEP_W
+#define RDF_DEEP_W 1
+#endif
+
 namespace {
 
 constexpr int kGroup = 4;          // trees walked interleaved by one lane (template GROUP: 1 and 2 for smaller forests)
@@ -125,6 +132,43 @@ struct alignas(64) LastLevelRec {
 };
 static_assert(sizeof(NodeRec16) == 16 && sizeof(NodeRec32) == 32 && sizeof(LastLevelRec) == 64, "record sizes");
 
+// ---- deep blocks: the levels whose records no cache holds, three levels to a 128-byte line ---------------------------
+// A forest whose deep levels are OCCUPIED (a trained forest; synth's "balanced" topology) visits practically every node of
+// them, so below the levels that fit an XCD's 4-MB L2 every node fetch of the heap-order table is a 128-byte line from
+// the Infinity Cache or HBM for 16 useful bytes: the bench batch on a balanced T4/D20 forest moves 0.67e9 such lines =
+// 86 GB per launch at 7.7 TB/s -- the fabric's whole bandwidth -- and takes 11.2 ms against 3.9 ms on the cache-resident
+// "full" topology (profiles/r04_*).  The packed forest therefore holds the hot records a second time, grouped by SUBTREE:
+//   * block of three levels, root on level R: records {root, left, right, LL, LR, RL, RR} = 112 bytes of one 128-byte line
+//     (the eighth slot is zero);
+//   * last block, root on level D - 2 (forests of up to four classes): {root, left, right} and the four leaf PDFs of
+//     level D - 1 {L.left, L.right, R.left, R.right}, 16 bytes each: a walk's last two node fetches AND its leaf fetch;
+//     forests of five to eight classes: root on level D - 1: {node, pad, left PDF (32 B), right PDF (32 B)}.
+// Block roots sit on levels R0 = D - 2 (or D - 1), R0 - 3, R0 - 6, ... >= 0; the blocks of one root level are contiguous,
+// [tree][root's index on its level], smaller root levels first; one all-zero line and a 64-byte trailer follow.
+// The kernel (k_eval_forest<..., DEEP>) walks the levels below `deep_from` (a root level, chosen per launch) from this
+// table, ONE TREE AFTER THE OTHER: a lane loads a whole block with seven back-to-back 16-byte loads (one line fill; the
+// L1 does not keep a line from one level to the next, measured in round 2), walks its three levels out of registers
+// (the record of the second and third level is picked by the sides taken: 16 v_cndmask per block) and moves on to the
+// next block -- a third of the lines from beyond L2 per walk, and the leaf comes with the last of them.
+// Usable from root level R on iff no node of a level >= R is flagged kFlagExact and (for the last block) every node
+// of level D - 1 has two leaves: k_pack leaves both facts in the trailer {1 + deepest level with an exact node,
+// nodes of level D - 1 that are not plain two-leaf nodes}.
+__host__ __device__ inline int deep_last_levels(int cpad) { return cpad == 4 ? 2 : 1; }
+__host__ __device__ inline bool deep_possible(int n_trees, int max_depth, int cpad)
+{
+    return n_trees >= 1 && (cpad == 4 || cpad == 8) && max_depth >= 5 && max_depth <= 27;
+}
+// lines of every block level whose root level is below R (R, Lmin members of the series R0 - 3 i)
+__host__ __device__ inline size_t deep_lines_before(int n_trees, int R, int Lmin)
+{
+    return (size_t)n_trees * ((((size_t)1 << R) - ((size_t)1 << Lmin)) / 7u);
+}
+__host__ __device__ inline size_t deep_total_lines(int n_trees, int max_depth, int cpad)   // without the zero line and the trailer
+{
+    const int R0 = max_depth - deep_last_levels(cpad);
+    return deep_lines_before(n_trees, R0, R0 % 3) + ((size_t)n_trees << R0);
+}
+
 struct EvalArgs {
     const uint16_t *depth;
     const float *forest;
@@ -155,6 +199,8 @@ struct EvalArgs {
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
     const uint4 *last_level;   // LastLevelRec [T][2^(D-1)] followed by the trailer (see k_pack), or null
     uint32_t last_level_min;   // deepest-level nodes in use from which the table is taken
+    const uint4 *deep;         // deep blocks (see above), or null
+    int deep_from;             // root level from which the walk takes the deep blocks (a member of the series; DEEP kernels)
     int cpad;                  // classes rounded up to a multiple of 4
     int filter_class;
     int check_empty;       // look at a tile's centre depths before staging it (throughput shape)
@@ -283,7 +329,7 @@ struct EvalArgsN {
     EvalArgs l[NL];
 };
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT, int NL = 1, bool TW = false>
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT, int NL = 1, bool TW = false, bool DEEP = false>
 // second launch bound = waves per SIMD the register allocation must allow: three 512-thread workgroups per CU are six
 // waves per SIMD (80 VGPRs; the 4-wide walk needs 86 without the bound and spills two dwords with it)
 __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgsN<NL> ka)
@@ -326,7 +372,16 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
         const uint2 t = *reinterpret_cast<const uint2 *>(a.last_level + (((size_t)a.T << (a.D - 1)) << 2));
         last_from_table = t.x == 0u && t.y >= a.last_level_min;
     }
-    const int walk_levels = last_from_table ? a.D - 1 : a.D;
+    // (deep blocks) the levels from a.deep_from on are walked block by block, one tree after the other, when the forest's
+    // deep table can serve them: the trailer's words, see "deep blocks" above
+    constexpr int kDeepLast = CMAX == 4 ? 2 : 1;           // levels in the last block
+    bool deep_on = false;
+    if (DEEP && a.deep) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(a.deep + ((deep_total_lines(a.T, a.D, a.cpad) + 1u) << 3));
+        deep_on = (uint32_t)a.deep_from >= t.x && t.y == 0u;
+    }
+    if (DEEP && deep_on) last_from_table = false;
+    const int walk_levels = (DEEP && deep_on) ? a.deep_from : last_from_table ? a.D - 1 : a.D;
     for (uint32_t i = tid; i < (uint32_t)a.T * lds_pitch; i += BLOCK) {
         const uint32_t k = i >> K, h = i & (lds_pitch - 1u);
         if (h == 0u) {      // slot 0: the all-zero node that finished tree slots fetch (see the level loop)
@@ -752,6 +807,183 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             h[k] = walking ? next : h[k];
                         }
                     }
+                    // ---- deep blocks: the levels from a.deep_from on, one tree after the other.  A lane loads the seven records of
+                    // its block -- one 128-byte line -- at once: one fill, and the L1 and L2 do not keep a line from one level
+                    // to the next (a record fetched later from the same line was a second fetch from beyond L2 every time:
+                    // profiles/r04_deep_variants.txt); it walks the block's levels out of registers -- the record of the
+                    // second and third level is picked by the sides taken -- and moves on to the next block.  The last block
+                    // brings the leaf PDFs of level D-1 along.  The PDFs are added tree after tree (the canonical order), in
+                    // round-to-nearest: the mode goes back and forth per tree.  A lane whose walk has ended reads the table's
+                    // all-zero line (offsets 0: its discarded probes are the pixel itself); one that ended above level D-1
+                    // takes its leaf from the PDF table. ----
+                    if (DEEP && deep_on) {
+                        const int R0 = a.D - kDeepLast, Lmin = R0 % 3;
+                        const size_t zero_at = deep_total_lines(a.T, a.D, a.cpad) << 7;
+                        const f2 r2 = {rcp_s, rcp_s};
+                        const f2 m2 = {kMagic, kMagic};
+                        constexpr int W = GROUP >= RDF_DEEP_W ? RDF_DEEP_W : 1;     // trees side by side
+#pragma unroll
+                        for (int k0 = 0; k0 < GROUP; k0 += W) {
+                            uint32_t hk[W];
+#pragma unroll
+                            for (int w = 0; w < W; ++w) hk[w] = k0 + w < GROUP ? h[k0 + w] : kIdle;
+                            // one level of the W trees: decode, every probe issued, then the decisions
+                            auto level = [&](const uint4 (&rec)[W]) {
+                                Node n[W];
+                                TileProbe qu[W], qv[W];
+#pragma unroll
+                                for (int w = 0; w < W; ++w) {
+                                    n[w] = decode_node(rec[w]);
+                                    const f2 nu = {n[w].ax, n[w].ay};
+                                    const f2 nv = {n[w].bx, n[w].by};
+                                    const f2 tu = __builtin_elementwise_fma(nu, r2, m2);
+                                    const f2 tv = __builtin_elementwise_fma(nv, r2, m2);
+                                    qu[w] = tprobe_issue(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky);
+                                    qv[w] = tprobe_issue(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky);
+                                }
+#pragma unroll
+                                for (int w = 0; w < W; ++w) {
+                                    const int g = tprobe_value(qu[w]) - tprobe_value(qv[w]) - (int)n[w].lo16;
+                                    const uint32_t next = walk_step(hk[w], g, n[w].w2, n[w].flags);
+                                    hk[w] = (int)hk[w] > 0 ? next : hk[w];
+                                }
+                            };
+                            // the seven records of the block of root level R a lane's walk stands on: wave-uniform base of the
+                            // tree's blocks of that level (the 2^R of a heap index folded in) + the lane's byte offset; the
+                            // all-zero line for a lane that is not walking
+                            uint4 q[7][W];
+                            auto load_block = [&](int R) {
+#pragma unroll
+                                for (int w = 0; w < W; ++w) {
+                                    const int tk = min(kb + k0 + w, a.T - 1);
+                                    const size_t base_at = (deep_lines_before(a.T, R, Lmin) + ((size_t)tk << R) - ((size_t)1 << R)) << 7;
+                                    const uint32_t off = (int)hk[w] > 0 ? hk[w] << 7 : (uint32_t)(zero_at - base_at);
+                                    const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.deep) + base_at + off);
+#pragma unroll
+                                    for (int i = 0; i < 7; ++i) q[i][w] = bp[i];
+                                }
+                                // (issued together -- the line is filled once -- before anything is decoded)
+#pragma unroll
+                                for (int w = 0; w < W; ++w)
+                                    asm volatile("" : "+v"(q[0][w].x), "+v"(q[1][w].x), "+v"(q[2][w].x), "+v"(q[3][w].x), "+v"(q[4][w].x),
+                                                      "+v"(q[5][w].x), "+v"(q[6][w].x));
+                            };
+                            auto any_walking = [&]() {
+                                bool any_w = false;
+#pragma unroll
+                                for (int w = 0; w < W; ++w) any_w |= (int)hk[w] > 0;
+                                return __any(any_w) != 0;
+                            };
+                            // records 3 .. 6 by the sides taken on the block's first two levels: 3 + 2 sa + sb
+                            auto third = [&](const bool (&sa)[W], uint4 (&out)[W]) {
+#pragma unroll
+                                for (int w = 0; w < W; ++w) {
+                                    const bool sb = (hk[w] & 1u) != 0u;
+                                    out[w] = select4(sa[w], select4(sb, q[6][w], q[5][w]), select4(sb, q[4][w], q[3][w]));
+                                }
+                            };
+                            uint4 rec[W];
+                            bool sa[W];
+                            for (int R = a.deep_from; R < R0; R += 3) {
+                                if (!any_walking()) break;
+                                load_block(R);
+                                level(q[0]);
+#pragma unroll
+                                for (int w = 0; w < W; ++w) {
+                                    sa[w] = (hk[w] & 1u) != 0u;
+                                    rec[w] = select4(sa[w], q[2][w], q[1][w]);
+                                }
+                                level(rec);
+                                third(sa, rec);
+                                level(rec);
+                            }
+                            // ---- the last block: the last two levels and their four leaf PDFs (five to eight classes: the last
+                            // level's node, a pad, its two 32-byte PDFs) ----
+                            bool have[W];               // this lane's walk reached level D-1 (every node there has two leaves)
+                            uint4 p0[W], p1[W];         // its leaf PDF (p1: classes 4-7)
+#pragma unroll
+                            for (int w = 0; w < W; ++w) { have[w] = false; p0[w] = p1[w] = make_uint4(0u, 0u, 0u, 0u); }
+                            if (any_walking()) {
+                                load_block(R0);
+                                if (CMAX == 4) {
+                                    level(q[0]);
+#pragma unroll
+                                    for (int w = 0; w < W; ++w) {
+                                        sa[w] = (hk[w] & 1u) != 0u;
+                                        have[w] = (int)hk[w] > 0;
+                                        rec[w] = select4(sa[w], q[2][w], q[1][w]);
+                                    }
+                                    level(rec);
+                                    third(sa, p0);
+                                } else {
+#pragma unroll
+                                    for (int w = 0; w < W; ++w) have[w] = (int)hk[w] > 0;
+                                    level(q[0]);
+#pragma unroll
+                                    for (int w = 0; w < W; ++w) {
+                                        const bool sb = (hk[w] & 1u) != 0u;
+                                        p0[w] = select4(sb, q[4][w], q[2][w]);
+                                        p1[w] = select4(sb, q[5][w], q[3][w]);
+                                    }
+                                }
+                            }
+                            // ---- the leaf PDFs of these trees, in tree order (the canonical order), in round-to-nearest; a walk that
+                            // ended above level D-1 takes its leaf from the PDF table ----
+                            bool early[W], any_early = false;
+#pragma unroll
+                            for (int w = 0; w < W; ++w) {
+                                early[w] = (int)hk[w] < 0 && hk[w] != kIdle && !have[w];
+                                any_early |= early[w];
+                            }
+                            if (__any(any_early)) {
+#pragma unroll
+                                for (int w = 0; w < W; ++w) {
+                                    const int tk = min(kb + k0 + w, a.T - 1);
+                                    // 16-byte rows: (((tree << D) + node) * 2 + side) * (cpad / 4), node * 2 + side = h & ~kDone (add_leaf_pdf)
+                                    const uint4 *row = reinterpret_cast<const uint4 *>(a.packed_pdf) +
+                                                       (early[w] ? (((size_t)tk << (a.D + 1)) + (hk[w] & ~kDone)) * (size_t)(a.cpad >> 2) : (size_t)0);
+                                    const uint4 e0 = row[0];
+                                    p0[w] = select4(early[w], e0, p0[w]);
+                                    if (CMAX == 8) {
+                                        const uint4 e1 = row[1];
+                                        p1[w] = select4(early[w], e1, p1[w]);
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int w = 0; w < W; ++w) {
+                                pin(p0[w].x); pin(p0[w].y); pin(p0[w].z); pin(p0[w].w);
+                                if (CMAX == 8) { pin(p1[w].x); pin(p1[w].y); pin(p1[w].z); pin(p1[w].w); }
+                            }
+                            set_round_nearest(p0[0].x);
+#pragma unroll
+                            for (int w = 0; w < W; ++w) {
+                                if (w > 0) pin(p0[w].x);
+                                pin(p0[w].y); pin(p0[w].z); pin(p0[w].w);
+                                if (CMAX == 8) { pin(p1[w].x); pin(p1[w].y); pin(p1[w].z); pin(p1[w].w); }
+                            }
+#pragma unroll
+                            for (int w = 0; w < W; ++w) {
+                                if (have[w] || early[w]) {
+                                    pdf[0] = pdf[0] + __uint_as_float(p0[w].x); pdf[1] = pdf[1] + __uint_as_float(p0[w].y);
+                                    pdf[2] = pdf[2] + __uint_as_float(p0[w].z); pdf[3] = pdf[3] + __uint_as_float(p0[w].w);
+                                    if constexpr (CMAX == 8) {
+                                        pdf[4] = pdf[4] + __uint_as_float(p1[w].x); pdf[5] = pdf[5] + __uint_as_float(p1[w].y);
+                                        pdf[6] = pdf[6] + __uint_as_float(p1[w].z); pdf[7] = pdf[7] + __uint_as_float(p1[w].w);
+                                    }
+                                    any_leaf = true;
+                                }
+                            }
+                            if (k0 + W < GROUP) {
+#pragma unroll
+                                for (int c = 0; c < CMAX; ++c) pin(pdf[c]);
+                                set_round_down(pdf[0]);
+#pragma unroll
+                                for (int c = 1; c < CMAX; ++c) pin(pdf[c]);
+                            }
+                        }
+                        continue;       // (next group of trees; the mode is round-to-nearest)
+                    }
                     // ---- level D-1 from the last-level table, one tree after the other: the node and both leaf PDFs of a
                     // tree come with one line fill and the side taken picks the PDF (every record of a usable table is an
                     // ordinary node with two leaves: no IEEE divide, no "continue").  A lane whose walk ended higher up
@@ -937,7 +1169,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 // ---- load-time repack: one thread per node; writes the 16-byte and the 32-byte table ----
 __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, NodeRec32 *packed32,
                                               float *packed_pdf, LastLevelRec *last_level, unsigned int *last_level_unusable,
-                                              int C, int cpad,
+                                              uint4 *deep, int n_trees, int C, int cpad,
                                               size_t total_slots, int D, int E, float s, int force_exact)
 {
     // slot = tree * 2^D + h, h = 1-based heap index (slot h == 0 of each tree is unused and zeroed)
@@ -950,6 +1182,10 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
         packed16[slot] = z16;
         packed32[slot] = z32;
         for (int c = 0; c < 2 * cpad; ++c) packed_pdf[slot * 2 * (size_t)cpad + c] = 0.f;
+        if (deep && tree == 0) {     // the all-zero line behind the blocks
+            uint4 *z = deep + (deep_total_lines(n_trees, D, cpad) << 3);
+            for (int i = 0; i < 8; ++i) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
         return;
     }
     const size_t i = tree * ((((size_t)1) << D) - 1) + (h - 1);
@@ -967,6 +1203,36 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     for (int c = 0; c < cpad; ++c) {
         q[c] = c < C ? p[7 + c] : 0.f;
         q[cpad + c] = c < C ? p[7 + C + c] : 0.f;
+    }
+    if (deep) {     // the node's place in the deep blocks (see "deep blocks" above)
+        const int R0 = D - deep_last_levels(cpad), Lmin = R0 % 3;
+        const int j = 63 - __clzll((unsigned long long)h);      // the node's level
+        if (j >= Lmin) {
+            const int R = j >= R0 ? R0 : R0 - 3 * ((R0 - j + 2) / 3);   // its block's root level
+            const int t = j - R;
+            const size_t line = deep_lines_before(n_trees, R, Lmin) + (tree << R) + ((h >> t) - ((size_t)1 << R));
+            uint4 *blk = deep + (line << 3);
+            const uint4 rec = make_uint4(h16.w[0], h16.w[1], h16.w[2], h16.w[3]);
+            const float4 *pq = reinterpret_cast<const float4 *>(q);
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            if (R == R0 && cpad == 8) {          // {node, pad, left PDF, right PDF}
+                blk[0] = rec; blk[1] = z; blk[6] = z; blk[7] = z;
+                for (int i = 0; i < 4; ++i) reinterpret_cast<float4 *>(blk)[2 + i] = pq[i];
+            } else {
+                blk[((1u << t) - 1u) + (uint32_t)(h & ((1u << t) - 1u))] = rec;
+                if (t == 0) blk[7] = z;
+                if (R == R0 && t == 1) {         // a node of level D-1 (cpad == 4): its two leaf PDFs
+                    const uint32_t c = (uint32_t)(h & 1u);
+                    reinterpret_cast<float4 *>(blk)[3 + 2 * c] = pq[0];
+                    reinterpret_cast<float4 *>(blk)[4 + 2 * c] = pq[1];
+                }
+            }
+            // trailer: word 0 = 1 + the deepest level that holds a kFlagExact node, word 1 = nodes of level D-1 that are not
+            // plain two-leaf nodes
+            unsigned int *tr = reinterpret_cast<unsigned int *>(deep + ((deep_total_lines(n_trees, D, cpad) + 1u) << 3));
+            if (n.flags & kFlagExact) atomicMax(tr, (unsigned)j + 1u);
+            if (j == D - 1 && (n.flags & 7u) != (kFlagLeftLeaf | kFlagRightLeaf)) atomicAdd(tr + 1, 1u);
+        }
     }
     const size_t first = (size_t)1 << (D - 1);
     if (last_level && h >= first) {     // (LastLevelRec; cpad == 4)
@@ -1270,10 +1536,10 @@ bool tile_at_lds_zero(const void *kernel)
     return hipFuncGetAttributes(&fa, kernel) == hipSuccess && fa.sharedSizeBytes == 0;
 }
 
-template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT>
+template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT, bool DEEP = false>
 int launch_one(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
-    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, GROUP, COMPACT>;
+    auto kern = k_eval_forest<BLOCK, PACKED, CMAX, STATS, GROUP, COMPACT, 1, false, DEEP>;
     const void *kp = reinterpret_cast<const void *>(kern);
     int per_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
@@ -1394,6 +1660,57 @@ int launch_block(bool packed, bool compact, const EvalArgs &a, int lds_bytes, in
     return launch_group<BLOCK, false, 16>(false, a, lds_bytes, cus, st);
 }
 
+// Launches that walk their deep levels from the deep blocks (packed forests of up to eight classes): the same choices of
+// workgroup size, classes in registers, trees per lane and pixel list as launch_block.
+template <int BLOCK, int CMAX>
+int launch_deep_c(bool compact, const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+{
+    if (compact) return launch_one<BLOCK, true, CMAX, false, 4, true, true>(a, lds_bytes, cus, st);
+    switch (group_for(a, true)) {
+    case 1:         // (a single tree walks the two-wide kernel with one slot idle: forests that big have more trees)
+    case 2: return launch_one<BLOCK, true, CMAX, false, 2, false, true>(a, lds_bytes, cus, st);
+    case 3: return launch_one<BLOCK, true, CMAX, false, 3, false, true>(a, lds_bytes, cus, st);
+    default: return launch_one<BLOCK, true, CMAX, false, 4, false, true>(a, lds_bytes, cus, st);
+    }
+}
+template <int BLOCK>
+int launch_deep(bool compact, const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
+{
+    return a.cpad == 4 ? launch_deep_c<BLOCK, 4>(compact, a, lds_bytes, cus, st) : launch_deep_c<BLOCK, 8>(compact, a, lds_bytes, cus, st);
+}
+
+// Where the deep blocks take over by default (no knob, no per-forest choice): 0 = never.  Measured on forests whose deep
+// levels are occupied (synth's balanced topology; DESIGN.md section 4, "deep blocks"): T4/D20 on the bench batch 11.2 ms with
+// the heap-order table, 9.1 / 7.8 / 7.8 / 9.8 ms with blocks from level 9 / 12 / 15 / 18; T8/D22 on config 5's shard
+// 38.4 ms against 25.8 / 24.8 / 24.9 / 27.0 ms from level 8 / 11 / 14 / 17.  So: forests whose hot records exceed what the L2s
+// and the Infinity Cache serve at the L1's pace (32 MB and more) take the blocks from the deepest root level that holds at
+// most 512 KB of heap-order records (an XCD's L2 keeps the levels above it).  A forest whose deep levels are NOT occupied
+// -- synth's "full" topology draws thresholds that send most pixels one way, its deep working set is a few megabytes --
+// is served faster by the heap-order table (3.9 against 5.9 ms): nothing in the records tells the two apart, which is
+// what rdf_forest_tune is for (it times both on the caller's frames and remembers the winner for that packed forest).
+int deep_default(int n_trees, int max_depth, int cpad, int K, bool big)
+{
+    if (!big) return 0;
+    if (((size_t)n_trees << max_depth) * sizeof(NodeRec16) < ((size_t)32 << 20)) return 0;
+    const int R0 = max_depth - deep_last_levels(cpad);
+    int from = R0;
+    while (from - 3 >= K && from - 3 >= 1) from -= 3;        // the smallest root level below LDS ...
+    while (from + 3 <= R0 && ((size_t)n_trees << (from + 3)) * sizeof(NodeRec16) <= ((size_t)512 << 10)) from += 3;   // ... up to 512 KB of records
+    return from;
+}
+
+// Per-forest choice (rdf_forest_set_deep_from / rdf_forest_tune): (device, packed table) -> level, 0 = never.
+std::map<std::pair<int, const void *>, int> g_forest_deep;
+
+int forest_deep_choice(const void *packed)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    const auto it = g_forest_deep.find(std::make_pair(dev, packed));
+    return it == g_forest_deep.end() ? -1 : it->second;
+}
+
 int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void *forest, int n_trees,
                  int max_depth, int n_classes, const void *labels, int r)
 {
@@ -1418,12 +1735,27 @@ static size_t last_level_bytes(int n_trees, int max_depth, int n_classes)
     return ((size_t)n_trees << (max_depth - 1)) * sizeof(LastLevelRec) + 64;
 }
 
+// the deep blocks behind the last-level table (128-byte aligned), one all-zero line and a 128-byte trailer
+static size_t deep_offset(int n_trees, int max_depth, int n_classes)
+{
+    const size_t before = ((size_t)n_trees << max_depth) *
+                              (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float)) +
+                          last_level_bytes(n_trees, max_depth, n_classes);
+    return (before + 127u) & ~(size_t)127u;
+}
+static size_t deep_bytes(int n_trees, int max_depth, int n_classes)
+{
+    if (!deep_possible(n_trees, max_depth, classes_padded(n_classes))) return 0;
+    return (deep_total_lines(n_trees, max_depth, classes_padded(n_classes)) + 2u) * 128u;
+}
+
 Knob g_halo{-1};
 Knob g_lds_levels{-1};
 Knob g_tree_waves{-1};
 Knob g_stage_vec{-1};
 Knob g_rows_per_wave{0};
 Knob g_force_exact{0};
+Knob g_deep_from{-1};                           // -1: deep blocks by forest size (eval_common); 0: never; > 0: from this level on (rounded up to a block root)
 Knob g_last_level_table{-1};                    // -1: level D-1 from the last-level table when it is usable and the forest uses half of that level; 1: whenever usable; 0: never
 
 // What eval_common works out before it launches: the kernel arguments (without a queue slot), the dynamic LDS and the
@@ -1598,6 +1930,25 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         const int pct = llt_knob == 1 ? 0 : env_int("RDF_LAST_LEVEL_MIN_PCT", 50);
         a.last_level_min = (uint32_t)((((unsigned long long)n_trees << (max_depth - 1)) * (unsigned long long)(pct < 0 ? 0 : pct > 100 ? 100 : pct)) / 100u);
     }
+    // deep blocks (k_eval_forest<..., DEEP>): from which root level on.  The knob or RDF_DEEP_FROM names a level (rounded up
+    // to a block root, and never inside the levels LDS holds); the default is in deep_default().
+    bool deep_launch = false;
+    if (packed && !tw && !stats && deep_bytes(n_trees, max_depth, n_classes) != 0) {
+        const int R0 = max_depth - deep_last_levels(a.cpad);
+        const int knob = g_deep_from;
+        int from = knob >= 0 ? knob : env_int("RDF_DEEP_FROM", -1);      // process-wide knob first,
+        if (from < 0) from = forest_deep_choice(packed);                 // then what was chosen for this packed forest,
+        if (from < 0) from = deep_default(n_trees, max_depth, a.cpad, K, big);   // then the default by forest size
+        if (from > 0) {
+            if (from < K) from = K;
+            if (from > R0) from = R0;
+            from = R0 - 3 * ((R0 - from) / 3);          // a root level: R0 - 3 i, rounded up
+            a.deep = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes));
+            a.deep_from = from;
+            deep_launch = (reinterpret_cast<uintptr_t>(a.deep) & 127u) == 0;
+            if (!deep_launch) a.deep = nullptr;
+        }
+    }
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
     a.lds_nodes_off = (uint32_t)tile_bytes;
     a.lds_mail_off = (uint32_t)(tile_bytes + node_bytes);
@@ -1624,6 +1975,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     }
     if (stats)   // (reference layout, 256 threads: eval_common chose both)
         return launch_one<256, false, 4, true, 4, false>(a, lds_bytes, cus, st);
+    if (deep_launch)
+        return block == 512 ? launch_deep<512>(compact_launch, a, lds_bytes, cus, st) : launch_deep<256>(compact_launch, a, lds_bytes, cus, st);
     return block == 512 ? launch_block<512>(packed != nullptr, compact_launch, a, lds_bytes, cus, st)
                         : launch_block<256>(packed != nullptr, compact_launch, a, lds_bytes, cus, st);
 }
@@ -1660,6 +2013,8 @@ int rdf_eval_tree(const uint16_t *depth, int n_img, int dim_x, int dim_y, const 
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes)
 {
     if (n_trees < 0 || max_depth < 0 || max_depth > 30 || n_classes < 0) return 0;
+    const size_t deep = deep_bytes(n_trees, max_depth, n_classes);
+    if (deep != 0) return deep_offset(n_trees, max_depth, n_classes) + deep;
     return ((size_t)n_trees << max_depth) *
            (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float)) +
            last_level_bytes(n_trees, max_depth, n_classes);
@@ -1685,11 +2040,26 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
         const hipError_t e = hipMemsetAsync(unusable, 0, 64, reinterpret_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
     }
+    {   // a re-packed table is another forest: its per-forest choice goes
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            std::lock_guard<std::mutex> lock(g_sched_mu);
+            g_forest_deep.erase(std::make_pair(dev, (const void *)packed));
+        }
+    }
+    uint4 *deep = nullptr;
+    if (deep_bytes(n_trees, max_depth, n_classes) != 0) {
+        deep = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(packed) + deep_offset(n_trees, max_depth, n_classes));
+        if ((reinterpret_cast<uintptr_t>(deep) & 127u) != 0) return RDF_ERR_BAD_ARG;     // `packed` must be 128-byte aligned
+        const hipError_t e = hipMemsetAsync(deep + ((deep_total_lines(n_trees, max_depth, classes_padded(n_classes)) + 1u) << 3), 0, 128,
+                                            reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        forest, reinterpret_cast<NodeRec16 *>(packed),
                        reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total),
                        reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32))),
-                       last_level, unusable, n_classes, classes_padded(n_classes), total,
+                       last_level, unusable, deep, n_trees, n_classes, classes_padded(n_classes), total,
                        max_depth, 7 + 2 * n_classes, scale_factor, (int)g_force_exact);
     return (int)hipGetLastError();
 }
@@ -1707,6 +2077,69 @@ int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_
     return eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees,
                        max_depth, n_classes, filter, filter_class, labels_out, labels_reduce, 1.0f, 0, nullptr,
                        stream);
+}
+
+int rdf_forest_set_deep_from(const void *packed, int level)
+{
+    if (!packed) return RDF_ERR_NULL_PTR;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    if (level < 0) g_forest_deep.erase(std::make_pair(dev, packed));
+    else g_forest_deep[std::make_pair(dev, packed)] = level;
+    return RDF_OK;
+}
+
+int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed, const float *forest,
+                    int n_trees, int max_depth, int n_classes, uint16_t *labels_scratch, int labels_reduce, void *stream,
+                    int *chosen_level, int *n_tried, int *levels_tried, float *ms_tried)
+{
+    if (!packed) return RDF_ERR_NULL_PTR;
+    if (max_depth > 27) return RDF_ERR_BAD_ARG;
+    const int cpad = classes_padded(n_classes);
+    // candidates: never, and every block root level from the first below the staged levels (about 6) down to the last block's
+    int cand[12], n_cand = 0;
+    cand[n_cand++] = 0;
+    if (deep_bytes(n_trees, max_depth, n_classes) != 0) {
+        const int R0 = max_depth - deep_last_levels(cpad);
+        for (int r = R0 % 3 + 6; r <= R0 && n_cand < 12; r += 3) cand[n_cand++] = r;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
+    int best = 0, rc = RDF_OK;
+    float best_ms = 0.f;
+    for (int c = 0; c < n_cand && rc == RDF_OK; ++c) {
+        rc = rdf_forest_set_deep_from(packed, cand[c]);
+        float ms_min = 0.f;
+        for (int rep = 0; rep < 4 && rc == RDF_OK; ++rep) {      // one warm-up, the fastest of three
+            (void)hipEventRecord(e0, st);
+            rc = eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees, max_depth, n_classes, nullptr, -1,
+                             labels_scratch, labels_reduce, 1.0f, 0, nullptr, stream);
+            (void)hipEventRecord(e1, st);
+            if (rc != RDF_OK) break;
+            e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) { rc = (int)e; break; }
+            if (rep >= 1 && (rep == 1 || ms < ms_min)) ms_min = ms;
+        }
+        if (levels_tried) levels_tried[c] = cand[c];
+        if (ms_tried) ms_tried[c] = ms_min;
+        if (rc == RDF_OK && (c == 0 || ms_min < best_ms)) { best = cand[c]; best_ms = ms_min; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != RDF_OK) {
+        rdf_forest_set_deep_from(packed, -1);
+        return rc;
+    }
+    if (n_tried) *n_tried = n_cand;
+    if (chosen_level) *chosen_level = best;
+    return rdf_forest_set_deep_from(packed, best);
 }
 
 int rdf_eval_forest_packed_filled(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
@@ -1917,6 +2350,7 @@ void rdf_set_stage_vec(int on) { g_stage_vec = on; }
 void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }
 void rdf_set_last_level_table(int on) { g_last_level_table = on; }
+void rdf_set_deep_from(int level) { g_deep_from = level; }
 
 int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved)
 {

@@ -99,6 +99,27 @@ class DecisionForest:
         self._packed[s] = (key, buf)
         return buf
 
+    def tune(self, depth_images_in, labels_reduce=1, scale_factor=1.):
+        """Chooses, by measurement on `depth_images_in` (device array [N, H, W] of representative frames), which table
+        serves this packed forest's deep levels -- heap-order records or the deep blocks, and from which level
+        (rdf_forest_tune, include/rdf_hip.h) -- and remembers it for the packed table of `scale_factor`.  Labels do
+        not depend on the choice.  Not in the reference.  Returns {"deep_from": level or 0, "tried": {level: ms}}."""
+        import ctypes
+        packed = self.packed(scale_factor)
+        if packed is None:
+            return {"deep_from": 0, "tried": {}}
+        rt = get_runtime()
+        lib = rt.lib
+        n, h, w = (int(v) for v in depth_images_in.shape)
+        scratch = DeviceArray((n, h // labels_reduce, w // labels_reduce), np.uint16)
+        chosen, tried = ctypes.c_int(0), ctypes.c_int(0)
+        levels, ms = (ctypes.c_int * 12)(), (ctypes.c_float * 12)()
+        _lib.check(lib, lib.rdf_forest_tune(device_ptr(depth_images_in), n, w, h, packed.ptr, device_ptr(self.forest_cu),
+                                            int(self.num_trees), int(self.max_depth), int(self.num_classes), scratch.ptr,
+                                            int(labels_reduce), rt.stream(), ctypes.byref(chosen), ctypes.byref(tried),
+                                            levels, ms), "rdf_forest_tune")
+        return {"deep_from": int(chosen.value), "tried": {int(levels[i]): round(float(ms[i]), 4) for i in range(tried.value)}}
+
 
 class LayeredDecisionForest:
     """Stack of forests evaluated in order, later layers optionally filtered on an earlier layer's

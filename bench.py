@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--trees", type=int, default=4)
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--classes", type=int, default=4)
-    ap.add_argument("--topology", default="full", choices=["full", "trained"])
+    ap.add_argument("--topology", default="full", choices=["full", "trained", "balanced"])
     ap.add_argument("--chunks", type=int, default=0, help="eval/gather pipeline chunks per step (0: one launch per step; at N>1 the gather then overlaps the NEXT step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -26,8 +26,10 @@ extern "C" {
 #endif
 
 /* 2: rdf_forest_packed_bytes grew (last-level table behind the three per-slot tables: re-pack with this library's
- * rdf_forest_pack); new: rdf_set_last_level_table, rdf_eval_forest_packed_filled.  Nothing was removed or re-typed. */
-#define RDF_ABI_VERSION 2
+ * rdf_forest_pack); new: rdf_set_last_level_table, rdf_eval_forest_packed_filled.  Nothing was removed or re-typed.
+ * 3: rdf_forest_packed_bytes grew again (deep blocks behind the last-level table; `packed` must be 128-byte aligned);
+ * new: rdf_set_deep_from, rdf_forest_set_deep_from, rdf_forest_tune.  Nothing was removed or re-typed. */
+#define RDF_ABI_VERSION 3
 
 #define RDF_OK 0
 #define RDF_ERR_BAD_ARG (-1)     /* negative size, labels_reduce < 1, max_depth outside [0,30] ... */
@@ -126,10 +128,32 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
  * are not ordinary nodes with two leaves, word 1 the records whose parent continues to them.  When word 0 is zero and
  * word 1 is at least half the level, a walk takes its last node and its leaf PDF from one cache line
  * (rdf_set_last_level_table); otherwise the table is ignored.
+ * Forests of up to eight classes and five or more levels carry a fifth table, 128-byte aligned: the hot records once more,
+ * grouped into three-level subtrees of seven records per 128-byte line, the last two levels together with their four leaf
+ * PDFs in one line (five to eight classes: the last level's node with its two PDFs), one all-zero line and a 128-byte
+ * trailer {1 + deepest level holding a node that needs the exact record, nodes of the last level that are not plain
+ * two-leaf nodes}.  Launches walk the levels no cache holds from it, a third of the line fetches per walk
+ * (rdf_set_deep_from).  `packed` must be 128-byte aligned.
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
                     float scale_factor, void *packed, void *stream);
+
+/*
+ * Which table serves a packed forest's deep levels is a property of the forest AND of the frames: a forest whose deep levels
+ * are occupied (a trained forest) walks them fastest from the deep blocks, one that sends most pixels down a few paths from
+ * the heap-order records, and nothing in the records tells the two apart.  rdf_forest_set_deep_from remembers a choice for
+ * one packed table on the current device (level > 0: deep blocks from that level on, 0: never, -1: forget -- the library's
+ * default by forest size); rdf_forest_pack into the same memory forgets it.  rdf_forest_tune makes the choice by
+ * measurement: it evaluates the caller's sample frames (device memory; results go to `labels_scratch`, uint16
+ * [n_img][dim_y/r][dim_x/r]) with every candidate -- never, and each block root level -- four launches each, keeps the
+ * fastest and reports what it tried (up to 12 entries in levels_tried / ms_tried, all three outputs nullable).  Synchronous.
+ * Labels do not depend on the choice.  The process-wide knob rdf_set_deep_from (>= 0) overrides both.
+ */
+int rdf_forest_set_deep_from(const void *packed, int level);
+int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed, const float *forest,
+                    int n_trees, int max_depth, int n_classes, uint16_t *labels_scratch, int labels_reduce, void *stream,
+                    int *chosen_level, int *n_tried, int *levels_tried, float *ms_tried);
 
 /* rdf_eval_forest on a packed table (hot records, exact records and leaf PDFs are all read from `packed`); `forest`
  * (original layout) is only used when `packed` is NULL for a degenerate forest (no tree or depth 0). */
@@ -355,6 +379,11 @@ void rdf_set_last_level_table(int on);   /* packed forests of up to four classes
                                             is an ordinary one with two leaves AND the forest uses at least half of the level
                                             (walks that mostly end higher up gain nothing); 1: whenever the nodes allow it;
                                             0: never */
+
+void rdf_set_deep_from(int level);       /* packed forests of up to eight classes can walk their deep levels from the deep blocks
+                                            (three levels per 128-byte line, one tree after the other): -1 = the library's
+                                            choice by forest size, 0 = never, > 0 = from this level on (rounded up to a block
+                                            root; never inside the levels held in LDS).  Same labels either way. */
 
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
 int rdf_event_create(void **event);

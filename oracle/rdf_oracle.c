@@ -306,6 +306,58 @@ int64_t rdf_oracle_order_sensitive(const uint16_t *depth, int n_img, int dim_x, 
     return sensitive;
 }
 
+/*
+ * Which nodes does a batch visit?  `visited` (uint8 [T][2^D - 1], level order like the forest) gets a 1 for every node
+ * record some evaluated pixel's walk reads -- the working set behind bench.py's per-level "distinct nodes" figures
+ * (how much of a level the workload really touches decides which cache serves it).  Same walk as
+ * rdf_oracle_eval_forest (labels_reduce, scale_factor, no filter); writes no labels.  Threads store the same value
+ * into a byte, so the races are benign.  Returns 0, or a negative value for bad arguments.
+ */
+int rdf_oracle_visit_map(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                         const float *forest, int n_trees, int max_depth, int n_classes,
+                         int labels_reduce, float scale_factor, uint8_t *visited, int n_threads)
+{
+    if (n_img < 0 || dim_x < 0 || dim_y < 0 || n_trees < 0 || max_depth < 0 || max_depth > 30 ||
+        n_classes < 0 || labels_reduce < 1 || !visited)
+        return -1;
+    const int lw = dim_x / labels_reduce, lh = dim_y / labels_reduce;
+    const int64_t per_img = (int64_t)lw * lh;
+    const int64_t total = per_img * n_img;
+    const int64_t nodes = ((int64_t)1 << max_depth) - 1;
+    const int E = 7 + 2 * n_classes;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = omp_get_max_threads();
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(n_threads)
+    for (int64_t i = 0; i < total; i++) {
+        const int img = (int)(i / per_img);
+        const int64_t rem = i % per_img;
+        const int32_t y = (int32_t)(rem / lw) * labels_reduce, x = (int32_t)(rem % lw) * labels_reduce;
+        const uint16_t *frame = depth + (size_t)img * dim_x * dim_y;
+        const uint16_t d = depth_at(frame, dim_x, dim_y, y, x);
+        if (d == 0 || d == RDF_NO_PIXEL) continue;
+        for (int k = 0; k < n_trees; k++) {
+            const float *tree = forest + (int64_t)k * nodes * E;
+            uint8_t *vis = visited + (int64_t)k * nodes;
+            int64_t g = 0;
+            for (int j = 0; j < max_depth; j++) {      /* the loop of walk(), with the node's index kept */
+                const int64_t at = (((int64_t)1 << j) - 1 + g);
+                const float *node = tree + at * (int64_t)E;
+                if (!vis[at]) vis[at] = 1;
+                const float f = feature(frame, dim_x, dim_y, x, y, d, node, scale_factor);
+                if (f < node[4]) {
+                    if (f2i_floor_sat(node[5]) == -1) g = g * 2; else break;
+                } else {
+                    if (f2i_floor_sat(node[6]) == -1) g = g * 2 + 1; else break;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 int rdf_oracle_max_threads(void)
 {
 #ifdef _OPENMP

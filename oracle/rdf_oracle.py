@@ -39,6 +39,8 @@ def lib():
         L.rdf_oracle_order_sensitive.argtypes = [p, i, i, i, p, i, i, i, i, f]
         L.rdf_oracle_order_sensitive.restype = ctypes.c_int64
         L.rdf_oracle_max_threads.restype = i
+        L.rdf_oracle_visit_map.argtypes = [p, i, i, i, p, i, i, i, i, f, p, i]
+        L.rdf_oracle_visit_map.restype = i
         _lib = L
     return _lib
 
@@ -134,6 +136,23 @@ def order_sensitive(depth, forest, labels_reduce=1, scale_factor=1.0):
     if r < 0:
         raise ValueError("rdf_oracle_order_sensitive: bad arguments (T must be 1..4)")
     return int(r)
+
+
+def distinct_nodes_per_level(depth, forest, labels_reduce=1, scale_factor=1.0, n_threads=0):
+    """int64 [T][D]: how many different nodes of each level of each tree the batch's walks read."""
+    depth = _c(depth, np.uint16)
+    forest = _c(forest, np.float32)
+    n, h, w = depth.shape
+    T, D, C = _forest_dims(forest)
+    vis = np.zeros((T, (1 << D) - 1), np.uint8)
+    rc = lib().rdf_oracle_visit_map(_ptr(depth), n, w, h, _ptr(forest), T, D, C, int(labels_reduce), float(scale_factor),
+                                    _ptr(vis), int(n_threads))
+    if rc != 0:
+        raise ValueError("rdf_oracle_visit_map: bad arguments")
+    out = np.zeros((T, D), np.int64)
+    for j in range(D):
+        out[:, j] = vis[:, (1 << j) - 1:(1 << (j + 1)) - 1].sum(axis=1, dtype=np.int64)
+    return out
 
 
 def max_threads():

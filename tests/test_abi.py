@@ -37,10 +37,19 @@ def test_binding_table_matches_header(rdf):
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
     assert lib.rdf_abi_version() == _lib.ABI_VERSION
-    # three tables per heap slot; up to four classes: the 64-byte records of the deepest level and a 64-byte trailer
-    assert lib.rdf_forest_packed_bytes(4, 20, 4) == (4 << 20) * (48 + 32) + (4 << 19) * 64 + 64
+    # three tables per heap slot; up to four classes: the 64-byte records of the deepest level and a 64-byte trailer; up to
+    # eight classes and five levels or more: the deep blocks (128-byte aligned), a zero line and a 128-byte trailer
+    def deep(T, D, last):       # lines: three-level blocks rooted on levels R0 - 3, R0 - 6, ... >= 0, then the last blocks
+        r0 = D - last
+        return T * (((1 << r0) - (1 << (r0 % 3))) // 7) + (T << r0) + 2
+
+    def up128(n):
+        return (n + 127) & ~127
+    assert lib.rdf_forest_packed_bytes(4, 20, 4) == up128((4 << 20) * (48 + 32) + (4 << 19) * 64 + 64) + deep(4, 20, 2) * 128
     assert lib.rdf_forest_packed_bytes(2, 1, 3) == (2 << 1) * (48 + 32)
-    assert lib.rdf_forest_packed_bytes(3, 10, 5) == (3 << 10) * (48 + 64)
+    assert lib.rdf_forest_packed_bytes(2, 4, 3) == (2 << 4) * (48 + 32) + (2 << 3) * 64 + 64
+    assert lib.rdf_forest_packed_bytes(3, 10, 5) == up128((3 << 10) * (48 + 64)) + deep(3, 10, 1) * 128
+    assert lib.rdf_forest_packed_bytes(3, 10, 9) == (3 << 10) * (48 + 96)
     assert b"2^31" in lib.rdf_error_string(-3)
 
 
@@ -53,12 +62,12 @@ def test_code_object_targets_gfx950(rdf):
 
 def test_code_object_stays_small(rdf, tmp_path):
     """Every instantiation of the forest kernel costs compile time and code size; the dispatch in rdf_hip.hip lists the
-    ones launches really take.  Fewer than 60 of them, and a library under 1.5 MB."""
+    ones launches really take.  Fewer than 70 of them (16 walk the deep blocks), and a library under 1.75 MB."""
     import shutil
     import subprocess
     from importlib import import_module
     so = import_module("3d-beats_amd._build").build()
-    assert os.path.getsize(so) < 1_500_000, os.path.getsize(so)
+    assert os.path.getsize(so) < 1_750_000, os.path.getsize(so)
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("no llvm-objdump")
@@ -71,7 +80,7 @@ def test_code_object_stays_small(rdf, tmp_path):
             out = subprocess.run([objdump, "-t", str(tmp_path / f)], capture_output=True, text=True).stdout
             kernels |= {l.split()[-1] for l in out.splitlines()
                         if "k_eval_forest" in l and " F " in l and not l.split()[-1].endswith(".kd")}
-    assert 0 < len(kernels) < 60, len(kernels)
+    assert 0 < len(kernels) < 70, len(kernels)
 
 
 def test_no_gpu_means_loud_failure_not_cpu_fallback(rdf):

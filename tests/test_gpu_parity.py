@@ -43,7 +43,6 @@ def test_native_library_is_the_one_loaded(rdf, gpu_runtime):
     assert gpu_runtime.name == "hip"
     maps = open("/proc/self/maps").read()
     assert "librdf_hip.so" in maps
-    assert "librdf_oracle" not in maps or True  # the oracle may be loaded by the test process as the checker
 
 
 def test_float_helpers_match_ieee(rdf, gpu_runtime):
@@ -418,6 +417,7 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
             lib.rdf_set_lds_budget_bytes(int(rng.choice([0, 1, 9000, 40000, 120000])))
             lib.rdf_set_tree_waves(int(rng.choice([-1, -1, 0, 1])))
             lib.rdf_set_last_level_table(int(rng.choice([-1, -1, 0])))
+            lib.rdf_set_deep_from(int(rng.choice([-1, 0, 1, 4, 7, 10])))
             want = np.full((n, h // r, w // r), prefill, np.uint16)
             oracle.eval_forest(depth, forest, want, r, filt, 2 if use_filter else None, s)
             for path in ("packed", "direct"):
@@ -434,6 +434,7 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
         lib.rdf_set_lds_budget_bytes(0)
         lib.rdf_set_tree_waves(-1)
         lib.rdf_set_last_level_table(-1)
+        lib.rdf_set_deep_from(-1)
 
 
 @pytest.mark.parametrize("trees,classes,r,topology", [(4, 4, 2, "full"), (4, 4, 1, "trained"), (3, 9, 2, "trained"), (2, 20, 1, "full"),
@@ -1095,3 +1096,138 @@ def test_filled_entry_point_equals_fill_then_evaluate(path, rdf, evs, oracle, gp
     assert lib.rdf_eval_forest_packed_filled(rdf.to_device(frames).ptr, 2, 90, 70, None, None, 0, 0, 4, None, -1, labels.ptr, 1,
                                              gpu_runtime.stream()) == 0
     assert np.all(labels.get() == 65535)
+
+
+# ---- deep blocks (k_eval_forest<..., DEEP>): the levels no cache holds, three to a 128-byte line ----
+
+def _deep_forest(rdf, topology, T, D, C, first_tree=0):
+    if topology == "balanced":
+        return rdf.synth.forest(T, D, C, "balanced", first_tree, calib=rdf.synth.calibration_frames(4, 120, 212))
+    return rdf.synth.forest(T, D, C, topology, first_tree)
+
+
+@pytest.mark.parametrize("topology,T,D,C", [("balanced", 4, 13, 4), ("trained", 4, 14, 4), ("balanced", 3, 12, 7), ("full", 8, 11, 3),
+                                            ("balanced", 1, 12, 2), ("trained", 2, 13, 8), ("trained", 6, 12, 5), ("balanced", 5, 11, 4)])
+def test_deep_blocks_give_the_oracles_labels(rdf, evs, oracle, gpu_runtime, topology, T, D, C):
+    """Every block root level as the place where the deep blocks take over, both workgroup sizes: the labels are the
+    oracle's (and the heap-order path's)."""
+    lib = gpu_runtime.lib
+    forest = _deep_forest(rdf, topology, T, D, C, first_tree=40)
+    depth = rdf.synth.frames(["dense", "live", "dense"], 700, 120, 212)
+    want = np.full(depth.shape, 65535, np.uint16)
+    oracle.eval_forest(depth, forest, want)
+    last = 2 if C <= 4 else 1
+    try:
+        for block in (0, 256, 512):
+            lib.rdf_set_block_threads(block)
+            for level in [0] + list(range((D - last) % 3, D - last + 1, 3)) + [D + 3]:
+                lib.rdf_set_deep_from(level)
+                got = _gpu_forest(rdf, evs["packed"], depth, forest, 65535)
+                assert np.array_equal(got, want), (block, level, int((got != want).sum()))
+    finally:
+        lib.rdf_set_block_threads(0)
+        lib.rdf_set_deep_from(-1)
+
+
+@pytest.mark.parametrize("r,use_filter,prefill", [(1, True, 65535), (2, False, 0), (2, True, 7), (3, False, 65535)])
+def test_deep_blocks_with_filter_reduce_and_prefill(rdf, evs, oracle, gpu_runtime, r, use_filter, prefill):
+    lib = gpu_runtime.lib
+    rng = np.random.default_rng(5)
+    forest = _deep_forest(rdf, "balanced", 4, 12, 4, first_tree=3)
+    depth = rdf.synth.frames(["live", "dense"], 900, 96, 200)
+    filt = rng.integers(0, 3, size=(2, 96 // r, 200 // r)).astype(np.uint16) if use_filter else None
+    want = np.full((2, 96 // r, 200 // r), prefill, np.uint16)
+    oracle.eval_forest(depth, forest, want, r, filt, 1 if use_filter else None, 0.5)
+    try:
+        for level in (4, 7, 10):
+            lib.rdf_set_deep_from(level)
+            got = _gpu_forest(rdf, evs["packed"], depth, forest, prefill, r, filt, 1 if use_filter else None, 0.5)
+            assert np.array_equal(got, want), (level, int((got != want).sum()))
+    finally:
+        lib.rdf_set_deep_from(-1)
+
+
+def test_deep_blocks_step_aside_for_nodes_they_cannot_serve(rdf, evs, oracle, gpu_runtime):
+    """A node that needs the IEEE divide below the take-over level, or a node of the last level that is not a plain
+    two-leaf node, makes the kernel take the heap-order path (the table's trailer says so): same labels."""
+    lib = gpu_runtime.lib
+    depth = rdf.synth.frames(["dense", "live"], 1300, 100, 180)
+    base = _deep_forest(rdf, "balanced", 4, 12, 4, first_tree=9)
+    cases = []
+    f1 = base.copy()
+    f1[1, (1 << 9) - 1 + 5, 0] = 3.0e7          # level 9: numerator beyond the integer record
+    cases.append(("exact node on level 9", f1))
+    f2 = base.copy()
+    f2[2, (1 << 11) - 1 + 17, 5] = -1.0         # level 11 (the last): left side says "continue" (tree_eval.cu:95-128: no leaf)
+    cases.append(("continue flag on the last level", f2))
+    f3 = base.copy()
+    f3[0, 0, 1] = np.inf                          # root: blocks from a deeper level stay usable
+    cases.append(("exact node on level 0", f3))
+    try:
+        for name, forest in cases:
+            want = np.full(depth.shape, 65535, np.uint16)
+            oracle.eval_forest(depth, forest, want)
+            for level in (0, 4, 7, 10):
+                lib.rdf_set_deep_from(level)
+                got = _gpu_forest(rdf, evs["packed"], depth, forest, 65535)
+                assert np.array_equal(got, want), (name, level, int((got != want).sum()))
+        lib.rdf_set_force_exact(1)
+        lib.rdf_set_deep_from(7)
+        want = np.full(depth.shape, 65535, np.uint16)
+        oracle.eval_forest(depth, base, want)
+        assert np.array_equal(_gpu_forest(rdf, evs["packed"], depth, base, 65535), want)
+    finally:
+        lib.rdf_set_force_exact(0)
+        lib.rdf_set_deep_from(-1)
+
+
+def test_forest_tune_picks_a_candidate_and_keeps_the_labels(rdf, evs, oracle, gpu_runtime):
+    """rdf_forest_tune times every candidate on the caller's frames, remembers the fastest for that packed table, and a
+    re-pack forgets it; labels never depend on the choice."""
+    lib = gpu_runtime.lib
+    forest_np = _deep_forest(rdf, "balanced", 4, 14, 4, first_tree=21)
+    depth_np = rdf.synth.frames(["dense", "live", "dense", "dense"], 1500, 120, 212)
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    depth = rdf.to_device(depth_np)
+    res = f.tune(depth)
+    assert set(res["tried"]) == {0, 6, 9, 12} and res["deep_from"] in res["tried"], res
+    assert all(ms > 0 for ms in res["tried"].values()), res
+    want = np.full(depth_np.shape, 65535, np.uint16)
+    oracle.eval_forest(depth_np, forest_np, want)
+    out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+    evs["packed"].get_labels_forest(f, depth, out)
+    assert np.array_equal(out.get(), want)
+    # an explicit choice for this table, then "forget"
+    packed = f.packed(1.0)
+    for level in (9, 0, -1):
+        assert lib.rdf_forest_set_deep_from(packed.ptr, level) == 0
+        out.fill(65535)
+        evs["packed"].get_labels_forest(f, depth, out)
+        assert np.array_equal(out.get(), want), level
+    assert lib.rdf_forest_set_deep_from(None, 3) != 0
+
+
+def test_balanced_topology_config2_full_size(rdf, evs, oracle, gpu_runtime):
+    """Config 2's frames on a T4/D20 forest whose deep levels are occupied (synth's balanced topology: median
+    thresholds over calibration frames), heap-order path and deep blocks: bit-exact, and the batch really visits most of the
+    deepest level."""
+    lib = gpu_runtime.lib
+    forest = rdf.synth.forest(4, 20, 4, "balanced")
+    depth = rdf.synth.frames(["dense", "live"], 0, 480, 848)
+    want = np.full(depth.shape, 65535, np.uint16)
+    st = np.zeros(3, np.uint64)
+    oracle.eval_forest(depth, forest, want, stats=st)
+    assert int(st[1]) == int(st[0]) * 4 * 20 and int(st[2]) == int(st[0]) * 4      # every walk reaches level D-1
+    distinct = oracle.distinct_nodes_per_level(depth, forest)
+    assert distinct[:, 19].min() > 0.45 * (1 << 19), distinct[:, 19]              # (the "full" topology: 1.7 %)
+    f = rdf.DecisionForest.from_numpy(forest)
+    d = rdf.to_device(depth)
+    try:
+        for level in (0, 12, 15, 18, -1):
+            lib.rdf_set_deep_from(level)
+            out = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
+            evs["packed"].get_labels_forest(f, d, out)
+            got = out.get()
+            assert np.array_equal(got, want), (level, int((got != want).sum()))
+    finally:
+        lib.rdf_set_deep_from(-1)

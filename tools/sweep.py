@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--filter", type=int, default=0, help="filter on a synthetic earlier layer whose class 1 covers 1/N of "
                     "the frame in 32x32 blocks (0: no filter)")
     ap.add_argument("--no-compaction", action="store_true")
+    ap.add_argument("--check", type=int, default=0, help="compare the first N frames' labels with the oracle")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=848)
     ap.add_argument("combos", nargs="*", default=["0:0", "256:32700", "512:54600"], help="0:0 = every default")
@@ -36,7 +37,8 @@ def main():
     rdf = importlib.import_module("3d-beats_amd")
     rt = rdf.get_runtime()
     lib = rt.lib
-    forest = rdf.DecisionForest.from_numpy(rdf.synth.forest(a.trees, a.depth, a.classes, a.topology))
+    forest_np = rdf.synth.forest(a.trees, a.depth, a.classes, a.topology)
+    forest = rdf.DecisionForest.from_numpy(forest_np)
     kinds = {"mixed": None, "interleaved": ["dense", "live"] * (a.frames // 2) + ["dense"] * (a.frames % 2),
              "dense": ["dense"] * a.frames, "live": ["live"] * a.frames}[a.kinds]
     host = (rdf.synth.mixed_batch(a.frames, 0, a.height, a.width) if kinds is None
@@ -51,7 +53,7 @@ def main():
         f2d = (((xx // 32 + yy // 32) % a.filter) == 0).astype(np.uint16)
         filt = rdf.to_device(np.broadcast_to(f2d, (host.shape[0],) + f2d.shape).copy())
     lib.rdf_set_compaction(0 if a.no_compaction else -1)
-    combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]   # block:lds[:rows_per_wave[:halo[:lds_levels[:stage_vec[:group]]]]]
+    combos = [tuple(int(x) for x in c.split(":")) for c in a.combos]   # block:lds[:rows_per_wave[:halo[:lds_levels[:stage_vec[:group[:deep_from]]]]]]
     res = {c: [] for c in combos}
     ref = None
     for r in range(a.rounds + 1):
@@ -63,6 +65,7 @@ def main():
             lib.rdf_set_lds_levels(c[4] if len(c) > 4 else -1)
             lib.rdf_set_stage_vec(c[5] if len(c) > 5 else -1)
             lib.rdf_set_group(c[6] if len(c) > 6 else 0)
+            lib.rdf_set_deep_from(c[7] if len(c) > 7 else -1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(a.reps):
@@ -75,10 +78,16 @@ def main():
                 got = labels.get()
                 ref = got if ref is None else ref
                 assert np.array_equal(got, ref), c
+    if a.check:
+        from oracle import rdf_oracle
+        n = min(a.check, host.shape[0])
+        want = np.full((n,) + ref.shape[1:], 65535, np.uint16)
+        rdf_oracle.eval_forest(host[:n], forest_np, want, red, None if filt is None else filt.get()[:n], 1 if filt is not None else None)
+        print(f"oracle check on {n} frames: {int((want != ref[:n]).sum())} differing pixels", flush=True)
     npx = a.frames * a.height * a.width
     for c in combos:
         v = np.array(res[c])
-        print(f"block {c[0]:5d} lds {c[1]:7d} rpw {c[2] if len(c) > 2 else 0} halo {c[3] if len(c) > 3 else -1:3d} levels {c[4] if len(c) > 4 else -1:2d} vec {c[5] if len(c) > 5 else -1:2d} group {c[6] if len(c) > 6 else 0}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
+        print(f"block {c[0]:5d} lds {c[1]:7d} rpw {c[2] if len(c) > 2 else 0} halo {c[3] if len(c) > 3 else -1:3d} levels {c[4] if len(c) > 4 else -1:2d} vec {c[5] if len(c) > 5 else -1:2d} group {c[6] if len(c) > 6 else 0} deep {c[7] if len(c) > 7 else -1:2d}: median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  "
               f"{npx / np.median(v) / 1e3:8.1f} Mpix/s", flush=True)
 
 
