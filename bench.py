@@ -69,7 +69,10 @@ def parse():
                     "forest, trained-like topology, per-hand pipeline, mean shift, training)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed batch (no other legs, no counters): "
                     "what tools/profile.sh traces so that rocprofv3's per-kernel average is the headline kernel's")
-    ap.add_argument("--leg", default=None, choices=["headline", "cfg2", "cfg5"],
+    ap.add_argument("--no-balanced", action="store_true", help="skip the legs on forests whose deep levels are occupied "
+                    "(cfg2_balanced, cfg5_balanced)")
+    ap.add_argument("--no-tune", action="store_true", help="do not let DecisionForest.tune choose the deep-level table per forest")
+    ap.add_argument("--leg", default=None, choices=["headline", "cfg2", "cfg5", "headline_balanced", "cfg5_balanced"],
                     help="internal: run ONE leg and print its kernel time (the program the --pmc passes profile)")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
     ap.add_argument("--scheduler", default="dynamic", choices=["dynamic", "static", "tile"],
@@ -165,9 +168,11 @@ def collect_counters(a, legs):
              "--cfg5-frames", str(a.cfg5_frames), "--cfg5-trees", str(a.cfg5_trees), "--cfg5-depth", str(a.cfg5_depth)] \
         + (["--unpacked"] if a.unpacked else [])
     for leg in legs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--steps", "3", "--warmup", "1"] + shape
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--steps", "3", "--warmup", "1"] + shape \
+            + (["--no-tune"] if a.no_tune else [])
         t0 = time.perf_counter()
-        name, vals, log = roofline.collect(cmd, "k_eval_forest", timeout=300, passes=roofline.PASSES)
+        # (the last launches of a pass are the timed ones: a leg first lets DecisionForest.tune try the other tables; cfg2 times 50)
+        name, vals, log = roofline.collect(cmd, "k_eval_forest", timeout=300, passes=roofline.PASSES, last_n=50 if leg == "cfg2" else 3)
         out[leg] = {"counters": vals, "kernel": name, "log": log, "seconds": round(time.perf_counter() - t0, 1),
                     "source": "rocprofv3 --pmc child passes of this run" if vals else None}
     return out
@@ -200,7 +205,8 @@ def main():
     # ---- counters first: the child passes must run before this process touches the GPU ----
     live = None
     if full_run and not a.no_counters:
-        legs = ["headline", "cfg2"] + ([] if a.no_cfg5 else ["cfg5"])
+        legs = ["headline", "cfg2"] + ([] if a.no_cfg5 else ["cfg5"]) + \
+               ([] if a.no_balanced else ["headline_balanced"] + ([] if a.no_cfg5 else ["cfg5_balanced"]))
         try:
             live = collect_counters(a, legs)
         except Exception as e:   # never let the profiler take the measurement down
@@ -240,15 +246,33 @@ def main():
     # config 5's per-GPU shard: dense 1280x720 frames, T8/D22/C4 full forest (512 MB of hot records: beyond the 256-MB
     # Infinity Cache), one launch per step; two frames compared with the oracle
     # ================================================================================================================
-    def leg_cfg5(steps, warmup, check):
+    def tune_forest(forest_obj, sample):
+        """Outside every timed region, like packing: which table serves the forest's deep levels (DecisionForest.tune)."""
+        if a.unpacked or a.no_tune:
+            return None
+        return forest_obj.tune(sample)
+
+    def distinct_nodes(frames_sample, forest_arr, cores):
+        """How much of every level the sample's walks really touch (oracle/rdf_oracle.c's visit map; summed over the trees)."""
+        from oracle import rdf_oracle
+        per = rdf_oracle.distinct_nodes_per_level(frames_sample, forest_arr, n_threads=cores)
+        n_trees = per.shape[0]
+        tot = per.sum(axis=0)
+        return {"frames": int(frames_sample.shape[0]), "per_level": [int(v) for v in tot],
+                "share_of_level": [round(float(v) / (n_trees << j), 4) for j, v in enumerate(tot)],
+                "hot_record_bytes_touched_below_level_6": int(tot[7:].sum()) * 16 if tot.shape[0] > 7 else 0}
+
+    def leg_cfg5(steps, warmup, check, topology="full"):
         F5, H5, W5, T5, D5, C5 = a.cfg5_frames, 720, 1280, a.cfg5_trees, a.cfg5_depth, 4
-        f_np = cached(f"forest_T{T5}_D{D5}_C{C5}_full", lambda: synth.forest(T5, D5, C5, "full"))
+        f_np = cached(f"forest_T{T5}_D{D5}_C{C5}_{topology}", lambda: synth.forest(T5, D5, C5, topology))
         fr_np = cached(f"frames_dense_{F5}_{H5}x{W5}_at5000", lambda: synth.frames(["dense"] * F5, 5000, H5, W5))
         forest5 = rdf.DecisionForest.from_numpy(np.asarray(f_np))
         depth5 = rdf.to_device(np.asarray(fr_np))
         lab5 = rdf.DeviceArray((F5, H5, W5), np.uint16).fill(65535)
+        tune5 = None
         if not a.unpacked:
             forest5.packed(1.0)
+            tune5 = tune_forest(forest5, depth5[0:min(8, F5)])
         for _ in range(warmup):
             ev.get_labels_forest(forest5, depth5, lab5)
         e5 = Events(rt, 2 * steps)
@@ -264,7 +288,8 @@ def main():
         e5.destroy()
         res = {"value": round(F5 * H5 * W5 / wall / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(wall * 1e3, 4),
                "kernel_ms": round(kms, 4), "steps": steps, "warmup": warmup,
-               "workload": f"{F5} dense {W5}x{H5} frames, T{T5}/D{D5}/C{C5} full forest (config 5's per-GPU shard), 1 GPU"}
+               "workload": f"{F5} dense {W5}x{H5} frames, T{T5}/D{D5}/C{C5} {topology} forest (config 5's per-GPU shard), 1 GPU",
+               "tune": tune5}
         if check:
             from oracle import rdf_oracle
             got = lab5[0:2].get()
@@ -280,12 +305,13 @@ def main():
             assert int(st[0]) == 2 * H5 * W5 and int(st[1]) == 2 * H5 * W5 * T5 * D5 and int(st[2]) == 2 * H5 * W5 * T5
             res["algorithmic_bytes"] = synth.algorithmic_bytes(F5, H5, W5, 1, False, C5,
                                                                [F5 * H5 * W5, F5 * H5 * W5 * T5 * D5, F5 * H5 * W5 * T5])
+            res["distinct_nodes"] = distinct_nodes(np.asarray(fr_np[0:2]), np.asarray(f_np), min(host_cores(), rdf_oracle.max_threads()))
         del forest5, depth5, lab5
         torch.cuda.empty_cache()
         return res
 
-    if a.leg == "cfg5":
-        print(json.dumps({"leg": "cfg5", **leg_cfg5(a.steps, a.warmup, False)}), flush=True)
+    if a.leg in ("cfg5", "cfg5_balanced"):
+        print(json.dumps({"leg": a.leg, **leg_cfg5(a.steps, a.warmup, False, "balanced" if a.leg == "cfg5_balanced" else "full")}), flush=True)
         return
 
     def leg_cfg5_all_ranks(steps, warmup):
@@ -405,13 +431,17 @@ def main():
     # headline workload
     # ================================================================================================================
     H, W, F, T, D, C = a.height, a.width, a.frames, a.trees, a.depth, a.classes
+    if a.leg == "headline_balanced":        # (the batch of the headline on the balanced forest: what the --pmc passes of cfg2_balanced profile)
+        a.topology, a.leg = "balanced", "headline"
     forest_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_{a.topology}", lambda: synth.forest(T, D, C, a.topology)))
     forest = rdf.DecisionForest.from_numpy(forest_np)
     frames_np = np.asarray(cached(f"frames_mixed_{F}_{H}x{W}_at{rank * F}", lambda: synth.mixed_batch(F, first_idx=rank * F, h=H, w=W)))
     depth = rdf.to_device(frames_np)
     labels = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
+    tune = None
     if not a.unpacked:
         forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
+        tune = tune_forest(forest, depth[0:min(16, F)])
 
     # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
     def leg_cfg2(n1, forest_obj=None):
@@ -642,7 +672,7 @@ def main():
     kern_med_ms = float(np.median(kern_ms))
 
     if a.leg == "headline":
-        print(json.dumps({"leg": "headline", "kernel_ms": round(kern_avg_ms, 4), "value": round(value, 2)}), flush=True)
+        print(json.dumps({"leg": "headline", "topology": a.topology, "kernel_ms": round(kern_avg_ms, 4), "value": round(value, 2), "tune": tune}), flush=True)
         return
 
     gather_mode = None if world == 1 else primary
@@ -657,8 +687,11 @@ def main():
     else:
         head = {"value": round(value, 2), "ms_per_step": round(mean_ms, 4), "ms_per_step_median": round(kern_med_ms, 4),
                 "value_is": "K steps between barriers, MAX over ranks, gather included"}
+    out_value_tmp = head["value"]
+    valid_px = int(stats[0])          # pixels the forest really evaluates (the rest is background / holes: tree_eval.cu:88-89)
     out = {
-        "metric": "classified Mpix/s on 848x480 depth frames (4 trees, depth 20); % HBM roofline",
+        "metric": "classified Mpix/s on 848x480 depth frames (4 trees, depth 20); % of the bounding roofline level "
+                  "(roofline.bound names it; the HBM level is roofline.levels.hbm.frac)",
         "value": head.pop("value"), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": head.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", **head,
@@ -670,7 +703,12 @@ def main():
                    "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": results[primary]["reserve"],
                    "gather": gather_mode,
                    "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if world > 1 else None)),
-                   "sharding": f"frames x{world}, forest replicated", "gather_check": results[primary]["gather_check"]},
+                   "sharding": f"frames x{world}, forest replicated", "gather_check": results[primary]["gather_check"],
+                   "deep_level_table": tune},
+        # the same rate counted over the pixels the forest really evaluates (this rank's batch: half of it is live-like
+        # frames, 85 % background); the metric counts every depth pixel
+        "value_valid_pixels": round(out_value_tmp * valid_px / (F * H * W), 2),
+        "valid_pixel_share": round(valid_px / (F * H * W), 4),
     }
     if world > 1:
         # what a driver needs to verify the run: N ranks of ONE RCCL communicator on N distinct devices
@@ -702,6 +740,10 @@ def main():
     out["roofline"] = roofline_for("headline", key, live, kern_avg_ms, alg_bytes)
     out["roofline"]["algorithmic"].update({"bytes_per_pixel": round(alg_bytes / (F * H * W), 1),
                                            "visits": {"pixels": int(stats[0]), "node_records": int(stats[1]), "leaves": int(stats[2])}})
+
+    # (top level: what bounds the headline kernel and how far the launch is from the HBM roofline)
+    out["bound"] = out["roofline"].get("bound")
+    out["hbm_frac"] = (out["roofline"].get("levels", {}).get("hbm") or {}).get("frac")
 
     if rank == 0 and full_run:
         # ---- what HBM really delivers to a plain stream: a 1-GB device-to-device copy ----
@@ -936,6 +978,54 @@ def main():
                         "parity": {"frames_checked": ns, "differing_pixels": mism, "checker": "oracle/rdf_oracle.c on the host"}})
             return res
 
+        def leg_balanced():
+            """Config 2 / config 4's shard on a forest whose deep levels are OCCUPIED (synth's balanced topology: every
+            threshold is the median of its feature over calibration frames, as a trained split is data-adapted; the
+            headline's "full" topology draws thresholds that send most pixels one way and touches 1.7 % of level 19): one
+            dense frame per launch, the batch rate, frames checked against the oracle, how much of each level the
+            batch really visits, and the roofline from this run's own counter passes."""
+            from oracle import rdf_oracle
+            fb_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_balanced", lambda: synth.forest(T, D, C, "balanced")))
+            fb = rdf.DecisionForest.from_numpy(fb_np)
+            fb.packed(1.0)
+            tune_b = tune_forest(fb, depth[0:min(16, F)])
+            res = leg_cfg2(200, fb)
+            lab_b = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
+            for _ in range(2):
+                ev.get_labels_forest(fb, depth, lab_b)
+            eb = Events(rt, 20)
+            for i in range(10):
+                eb.record(2 * i)
+                ev.get_labels_forest(fb, depth, lab_b)
+                eb.record(2 * i + 1)
+            ms_b = float(np.median([eb.elapsed_ms(2 * i, 2 * i + 1) for i in range(10)]))
+            eb.destroy()
+            ns = min(8, F)
+            cores = min(host_cores(), rdf_oracle.max_threads())
+            want = np.full((ns, H, W), 65535, np.uint16)
+            st = np.zeros(3, np.uint64)
+            tc = time.perf_counter()
+            rdf_oracle.eval_forest(frames_np[0:ns], fb_np, want, n_threads=cores, stats=st)
+            t_cpu = time.perf_counter() - tc
+            mism = int((want != lab_b[0:ns].get()).sum())
+            assert mism == 0, f"balanced topology: GPU labels differ from the oracle in {mism} pixels"
+            # every walk of this topology reaches level D-1: the batch's visit counters are the headline's
+            alg_b = synth.algorithmic_bytes(F, H, W, 1, False, C, [int(stats[0]), int(stats[0]) * T * D, int(stats[0]) * T])
+            res.update({"topology": "balanced", "tune": tune_b,
+                        "batch": {"value": round(F * H * W / ms_b / 1e3, 2), "unit": "Mpix/s", "ms_per_step": round(ms_b, 4),
+                                  "value_valid_pixels": round(int(stats[0]) / ms_b / 1e3, 2), "frames": F, "steps": 10},
+                        "parity": {"frames_checked": ns, "differing_pixels": mism, "checker": "oracle/rdf_oracle.c on the host"},
+                        "cpu_baseline": {"value": round(ns * H * W / t_cpu / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+                                         "sample": f"one pass over the batch's first {ns} frames, {t_cpu:.2f} s"},
+                        "distinct_nodes": distinct_nodes(frames_np[0:ns], fb_np, cores),
+                        "distinct_nodes_full_topology": distinct_nodes(frames_np[0:ns], forest_np, cores) if a.topology == "full" else None})
+            res["batch"]["roofline"] = roofline_for("headline_balanced", f"F{F}_T{T}_D{D}_C{C}_balanced", live, ms_b, alg_b)
+            return res
+
+        if not a.no_balanced and not a.unpacked:
+            leg("cfg2_balanced", leg_balanced)
+            out["value_balanced"] = (out["cfg2_balanced"].get("batch") or {}).get("value")
+
         if not a.no_extra_legs:
             import bench_legs
             leg("unpacked", leg_unpacked)
@@ -953,6 +1043,14 @@ def main():
             c5["roofline"] = roofline_for("cfg5", f"F{a.cfg5_frames}_T{a.cfg5_trees}_D{a.cfg5_depth}_C4_full_1280x720", live, c5["kernel_ms"],
                                           c5.pop("algorithmic_bytes", None))
             out["cfg5_shard"] = c5
+            if not a.no_balanced and not a.unpacked:
+                try:
+                    c5b = leg_cfg5(5, 2, True, "balanced")
+                    c5b["roofline"] = roofline_for("cfg5_balanced", f"F{a.cfg5_frames}_T{a.cfg5_trees}_D{a.cfg5_depth}_C4_balanced_1280x720", live,
+                                                   c5b["kernel_ms"], c5b.pop("algorithmic_bytes", None))
+                except Exception as e:   # noqa: BLE001 -- the headline is measured; it must still be printed
+                    c5b = {"error": f"{type(e).__name__}: {e}"[:400]}
+                out["cfg5_balanced"] = c5b
         if live:
             out["counter_passes"] = {leg: {"seconds": v["seconds"], "log": v["log"]} for leg, v in live.items()}
 

@@ -18,9 +18,11 @@ class _OracleLib:
     def __init__(self):
         self._o = rdf_oracle.lib()
         self.calls = []
+        self.trace = []          # (entry point, every argument as passed): tests/test_callconv.py reads the buffer wiring from it
         self._packed_scale = {}
 
     def rdf_eval_forest(self, depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, stream):
+        self.trace.append(("rdf_eval_forest", (depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, stream,)))
         self.calls.append(("rdf_eval_forest", n_img, dim_x, dim_y, T, D, C, fcls, r, float(s)))
         rc = self._o.rdf_oracle_eval_forest(depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, None, 0)
         return 0 if rc == 0 else -1
@@ -31,6 +33,7 @@ class _OracleLib:
         return 0 if rc == 0 else -1
 
     def rdf_eval_tree(self, depth, n_img, dim_x, dim_y, tree, D, C, out, stream):
+        self.trace.append(("rdf_eval_tree", (depth, n_img, dim_x, dim_y, tree, D, C, out, stream,)))
         self.calls.append(("rdf_eval_tree", n_img, dim_x, dim_y, D, C))
         rc = self._o.rdf_oracle_eval_tree(depth, n_img, dim_x, dim_y, tree, D, C, out, 0)
         return 0 if rc == 0 else -1
@@ -44,6 +47,7 @@ class _OracleLib:
         return 0
 
     def rdf_eval_forest_packed(self, depth, n_img, dim_x, dim_y, packed, forest, T, D, C, filt, fcls, out, r, stream):
+        self.trace.append(("rdf_eval_forest_packed", (depth, n_img, dim_x, dim_y, packed, forest, T, D, C, filt, fcls, out, r, stream,)))
         s = self._packed_scale[int(packed)]
         self.calls.append(("rdf_eval_forest_packed", n_img, dim_x, dim_y, T, D, C, fcls, r, s))
         rc = self._o.rdf_oracle_eval_forest(depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, out, r, s, None, 0)
@@ -54,6 +58,7 @@ class _OracleLib:
         return self.rdf_eval_forest_packed(depth, n_img, dim_x, dim_y, packed, forest, T, D, C, filt, fcls, out, r, stream)
 
     def rdf_composite(self, images, n_images, dim_x, dim_y, cond, n_cond, out, bad, stream):
+        self.trace.append(("rdf_composite", (images, n_images, dim_x, dim_y, cond, n_cond, out, bad, stream,)))
         self.calls.append(("rdf_composite", n_images, dim_x, dim_y, n_cond))
         nb = ctypes.c_int64(0)
         rc = self._o.rdf_oracle_composite(images, n_images, dim_x, dim_y, cond, n_cond, out, ctypes.byref(nb))
@@ -63,6 +68,7 @@ class _OracleLib:
 
     def rdf_layered_run(self, depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes,
                         filter_layer, filter_class, layer_labels, table_dev, cond, n_cond, out, bad, r, s, stream):
+        self.trace.append(("rdf_layered_run", (depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes, filter_layer, filter_class, layer_labels, table_dev, cond, n_cond, out, bad, r, s, stream,)))
         self.calls.append(("rdf_layered_run", dim_x, dim_y, n_layers, r, float(s)))
         lw, lh = dim_x // r, dim_y // r
         self.rdf_fill_u16(out, lw * lh, 65535, 0)
@@ -79,6 +85,7 @@ class _OracleLib:
         return self.rdf_composite(table_dev, n_layers, lw, lh, cond, n_cond, out, bad, stream)
 
     def rdf_fill_u16(self, dst, n, value, stream):
+        self.trace.append(("rdf_fill_u16", (dst, n, value, stream,)))
         self.calls.append(("rdf_fill_u16", int(n), int(value)))
         arr = (ctypes.c_uint16 * int(n)).from_address(int(dst))
         np.frombuffer(arr, dtype=np.uint16)[:] = value

@@ -1,0 +1,140 @@
+"""Rows H-K against the reference's OWN Python: tests/golden/callconv_v1.json was recorded by running
+/root/reference/src/decision_tree.py on stand-in pycuda / OpenGL modules (tests/golden/make_callconv_golden.py, build
+container only); here the same scenarios run through this repo's package on the host test double and must issue the same
+sequence -- fills, forest evaluations in layer order, composite -- with the same buffers in the same roles and the same
+scalars.  Plumbing, not arithmetic (the arithmetic is the oracle's job)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "callconv_v1.json")))
+SCEN = {s["scenario"]: s for s in FIX["scenarios"]}
+
+
+def _ref_events(name):
+    """The reference's recording in a launch-geometry-free form."""
+    out = []
+    for e in SCEN[name]["events"]:
+        if e["op"] == "fill":
+            out.append(("fill", e["buffer"], int(np.prod(e["shape"])), e["value"]))
+        elif e["op"] == "launch" and e["kernel"] == "evaluate_image_using_forest":
+            v = [a.get("scalar", a.get("buffer")) for a in e["args"]]
+            T, n_img, dim_x, dim_y, C, D, bdx, depth, fcls, filt, forest, labels, r, s = v
+            assert bdx == FIX["MAX_THREADS_PER_BLOCK"] // T and e["block"] == [bdx, T, 1] and e["shared"] == bdx * C * 4
+            assert e["grid"] == [n_img * (dim_y // r) * (dim_x // r) // bdx + 1, 1, 1]
+            assert [a["dtype"] for a in e["args"] if "scalar" in a] == ["int32"] * 8 + ["int32", "float32"]
+            out.append(("forest", depth, forest, filt if fcls != -1 else None, fcls, labels, T, n_img, dim_x, dim_y, C, D, r, s))
+        elif e["op"] == "launch" and e["kernel"] == "evaluate_image_using_tree":
+            n_img, dim_x, dim_y, C, D, depth, tree, labels = [a.get("scalar", a.get("buffer")) for a in e["args"]]
+            assert e["block"] == [1024, 1, 1] and e["grid"] == [n_img * dim_y * dim_x // 1024 + 1, 1, 1]
+            out.append(("tree", depth, tree, labels, n_img, dim_x, dim_y, C, D))
+        elif e["op"] == "launch" and e["kernel"] == "make_composite_labels_image":
+            images, n, dim_x, dim_y, cond, out_img = [a.get("scalar", a.get("buffer")) for a in e["args"]]
+            assert e["block"] == [32, 32, 1] and e["grid"] == [dim_x // 32 + 1, dim_y // 32 + 1, 1]
+            out.append(("composite", images, n, dim_x, dim_y, cond, out_img))
+    return out
+
+
+def _my_events(trace, roles):
+    """The package's calls into the C ABI (tests/fake_runtime.py's trace) in the same form."""
+    def who(p):
+        return None if p is None else roles.get(int(p), f"unknown@{int(p):#x}")
+    out = []
+    for name, a in trace:
+        if name == "rdf_fill_u16":
+            out.append(("fill", who(a[0]), int(a[1]), int(a[2])))
+        elif name == "rdf_eval_forest":
+            depth, n_img, dim_x, dim_y, forest, T, D, C, filt, fcls, labels, r, s, _ = a
+            out.append(("forest", who(depth), who(forest), who(filt) if fcls != -1 else None, fcls, who(labels), T, n_img, dim_x, dim_y, C, D, r, float(s)))
+        elif name == "rdf_eval_tree":
+            depth, n_img, dim_x, dim_y, tree, D, C, labels, _ = a
+            out.append(("tree", who(depth), who(tree), who(labels), n_img, dim_x, dim_y, C, D))
+        elif name == "rdf_composite":
+            images, n, dim_x, dim_y, cond, n_cond, out_img, bad, _ = a
+            out.append(("composite", who(images), n, dim_x, dim_y, who(cond), who(out_img)))
+    return out
+
+
+def test_fixture_is_data_only():
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "callconv_v1.json")).read()
+    assert "def " not in text and "import " not in text and "__global__" not in text
+
+
+def test_get_config_and_constructors(rdf, host_runtime):
+    for key, want in FIX["get_config"].items():
+        d, c = (int(v) for v in key.split(","))
+        assert list(rdf.DecisionTree.get_config(d, c)) == want
+    s = SCEN["constructors"]
+    f = rdf.DecisionForest(4, 6, 4)
+    assert list(f.forest_cu.shape) == s["forest_shape"] and f.forest_cu.dtype == np.float32
+    assert {k: int(getattr(f, k)) for k in s["forest_attrs"]} == s["forest_attrs"]
+    assert not f.forest_cu.get().any()                      # the reference fills its tables with 0.0f
+    t = rdf.DecisionTree(5, 3)
+    assert list(t.tree_out_cu.shape) == s["tree_shape"] and not t.tree_out_cu.get().any()
+
+
+def test_flat_entry_points_issue_the_reference_calls(rdf, host_runtime):
+    ev = rdf.DecisionTreeEvaluator(use_packed=False)
+    lib = host_runtime.lib
+    tree = rdf.DecisionTree(5, 3)
+    depth, labels = rdf.DeviceArray((2, 48, 64), np.uint16).fill(1000), rdf.DeviceArray((2, 48, 64), np.uint16).fill(65535)
+    del lib.trace[:]
+    ev.get_labels(tree, depth, labels)
+    roles = {depth.ptr: "depth", labels.ptr: "labels", tree.tree_out_cu.ptr: "tree"}
+    assert _my_events(lib.trace, roles) == _ref_events("get_labels")
+
+    f4 = rdf.DecisionForest(4, 6, 4)
+    depth3, lab3 = rdf.DeviceArray((3, 48, 64), np.uint16).fill(1000), rdf.DeviceArray((3, 48, 64), np.uint16).fill(65535)
+    del lib.trace[:]
+    ev.get_labels_forest(f4, depth3, lab3)
+    roles = {depth3.ptr: "depth", lab3.ptr: "labels", f4.forest_cu.ptr: "forest"}
+    assert _my_events(lib.trace, roles) == _ref_events("get_labels_forest_r1")
+
+    lab3h, filt = rdf.DeviceArray((3, 24, 32), np.uint16).fill(65535), rdf.DeviceArray((3, 24, 32), np.uint16).fill(2)
+    del lib.trace[:]
+    ev.get_labels_forest(f4, depth3, lab3h, labels_reduce=2, filter_images=filt, filter_images_class=2, scale_factor=0.5)
+    roles = {depth3.ptr: "depth", lab3h.ptr: "labels", filt.ptr: "filter", f4.forest_cu.ptr: "forest"}
+    assert _my_events(lib.trace, roles) == _ref_events("get_labels_forest_r2_filter")
+
+    f3 = rdf.DecisionForest(3, 7, 7)
+    del lib.trace[:]
+    ev.get_labels_forest(f3, depth3, lab3, 1, None, None, 2.0)      # positional, as the reference's signature has it
+    roles = {depth3.ptr: "depth", lab3.ptr: "labels", f3.forest_cu.ptr: "forest"}
+    assert _my_events(lib.trace, roles) == _ref_events("get_labels_forest_three_trees_positional")
+
+
+@pytest.mark.parametrize("label", ["layered_two_layers", "layered_three_layers"])
+def test_layered_forest_issues_the_reference_sequence(rdf, host_runtime, tmp_path, label):
+    run = SCEN[label + "_run"]
+    init = SCEN[label + "_init"]
+    for fn, shp in run["forest_shapes"].items():
+        np.save(tmp_path / fn, np.zeros(shp, np.float32))
+    cfg_path = tmp_path / (label + ".json")
+    cfg_path.write_text(json.dumps(run["config"]))
+    lf = rdf.LayeredDecisionForest.load(str(cfg_path), tuple(run["depth_dims"]), run["labels_reduce"])
+    lf.fused = False                    # the reference's sequence, launch for launch (the one-call path is checked against it on the GPU)
+    lf.eval.use_packed = False
+    # what __init__ leaves behind
+    assert list(lf.labels_dims) == init["labels_dims"] and list(lf.depth_dims) == init["depth_dims"]
+    assert lf.num_models == init["num_models"] and lf.num_layered_classes == init["num_layered_classes"]
+    assert [[m.num_trees, m.max_depth, m.num_classes, fm, fc] for m, fm, fc in lf.m] == init["layers"]
+    sets = {e["buffer"]: e for e in init["events"] if e["op"] == "set"}
+    roles = {rdf.device_ptr(b): f"layer{i}_labels" for i, b in enumerate(lf.label_images)}
+    assert [roles[int(p)] for p in lf.labels_images_ptrs_cu.cu().get()] == sets["label_pointer_table"]["values_as_roles"]
+    assert lf.labels_images_ptrs_cu.cu().dtype == np.int64
+    assert lf.labels_conditions_cu.cu().get().reshape(-1).tolist() == sets["conditions"]["small_values"]
+    assert lf.labels_conditions_cu.cu().dtype == np.int32 and list(lf.labels_conditions_cu.shape) == sets["conditions"]["shape"]
+    assert list(lf.label_colors.shape) == sets["label_colors"]["shape"] and lf.label_colors.cu().dtype == np.uint8
+    # run()
+    depth_image = rdf.GpuBuffer(tuple(run["depth_dims"]), np.uint16)
+    labels_image = rdf.GpuBuffer(lf.labels_dims, np.uint16)
+    depth_image.cu().fill(1000)
+    roles.update({rdf.device_ptr(depth_image): "depth_image", rdf.device_ptr(labels_image): "labels_image",
+                  rdf.device_ptr(lf.labels_images_ptrs_cu): "label_pointer_table", rdf.device_ptr(lf.labels_conditions_cu): "conditions"})
+    roles.update({m.forest_cu.ptr: f"layer{i}_forest" for i, (m, _, _) in enumerate(lf.m)})
+    lib = host_runtime.lib
+    del lib.trace[:]
+    lf.run(depth_image, labels_image, run["scale_factor"])
+    assert _my_events(lib.trace, roles) == _ref_events(label + "_run")

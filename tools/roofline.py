@@ -65,32 +65,35 @@ PASSES = [
 ]
 
 
-def parse_counters(root, kernel_substr):
+def parse_counters(root, kernel_substr, last_n=None):
     """Mean of every counter over the dispatches of the most frequently launched kernel whose name contains
-    `kernel_substr` (rocprofv3 --pmc --output-format csv trees under `root`)."""
+    `kernel_substr` (rocprofv3 --pmc --output-format csv trees under `root`).  With `last_n`: over the LAST n dispatches of
+    kernels whose name contains `kernel_substr` in each pass -- the timed launches of a program that first tries other
+    launches of the same kernel family (DecisionForest.tune); the kernel named is the one those dispatches ran."""
     acc = {}
     for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
-            for row in csv.DictReader(fh):
-                k = row.get("Kernel_Name", "")
-                if kernel_substr not in k:
-                    continue
-                d = acc.setdefault(k, {})
-                d.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-                try:    # the dispatch's own duration in this (profiled) pass, for the clock estimate
-                    d.setdefault("_ns:" + row["Counter_Name"], []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
-                    d.setdefault("_vgpr", []).append(float(row["VGPR_Count"]))
-                    d.setdefault("_lds_bytes", []).append(float(row["LDS_Block_Size"]))
-                    d.setdefault("_grid", []).append(float(row["Grid_Size"]))
-                except (KeyError, ValueError):
-                    pass
+            rows = [row for row in csv.DictReader(fh) if kernel_substr in row.get("Kernel_Name", "")]
+        if last_n:
+            ids = sorted({int(row["Dispatch_Id"]) for row in rows})[-last_n:]
+            rows = [row for row in rows if int(row["Dispatch_Id"]) in ids]
+        for row in rows:
+            d = acc.setdefault(row["Kernel_Name"], {})
+            d.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            try:    # the dispatch's own duration in this (profiled) pass, for the clock estimate
+                d.setdefault("_ns:" + row["Counter_Name"], []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                d.setdefault("_vgpr", []).append(float(row["VGPR_Count"]))
+                d.setdefault("_lds_bytes", []).append(float(row["LDS_Block_Size"]))
+                d.setdefault("_grid", []).append(float(row["Grid_Size"]))
+            except (KeyError, ValueError):
+                pass
     if not acc:
         return None, {}
     name = max(acc, key=lambda k: max(len(v) for v in acc[k].values()))
     return name, {c: sum(v) / len(v) for c, v in acc[name].items()}
 
 
-def collect(cmd, kernel_substr, timeout=240, passes=PASSES, keep_dir=None):
+def collect(cmd, kernel_substr, timeout=240, passes=PASSES, keep_dir=None, last_n=None):
     """Runs `cmd` (a list, the program itself first: rocprofv3 must not be handed a launcher) once per counter set under
     rocprofv3 --pmc and returns (kernel name, {counter: mean per launch}, log lines).  Each pass is its own process; a
     pass that fails or times out is skipped.  Call this BEFORE the calling process touches the GPU."""
@@ -111,7 +114,7 @@ def collect(cmd, kernel_substr, timeout=240, passes=PASSES, keep_dir=None):
         except Exception as e:  # timeout, missing tool
             log.append(f"pass {tag}: {type(e).__name__}: {e}")
             continue
-        k, vals = parse_counters(d, kernel_substr)
+        k, vals = parse_counters(d, kernel_substr, last_n)
         if vals:
             name = name or k
             out.update(vals)
@@ -189,6 +192,8 @@ def model(counters, kernel_ms, alg_bytes=None, cus=CUS):
                                   "tools/ubench_valu.hip) per SIMD against the kernel's cycles"}
     out = {"kernel_ms": round(kernel_ms, 4), "clock_ghz": round(clk / 1e9, 3) if clk else None, "traffic": int(hbm) if hbm else None,
            "levels": levels}
+    if c.get("TCC_REQ_sum"):
+        out["l2_hit_rate"] = round(c.get("TCC_HIT_sum", 0.0) / c["TCC_REQ_sum"], 4)
     if levels:
         b = max(levels, key=lambda k: levels[k]["frac"])
         out.update({"bound": b, "achieved": levels[b]["achieved"], "peak": levels[b]["peak"], "unit": levels[b]["unit"],
