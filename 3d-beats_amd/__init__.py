@@ -12,7 +12,7 @@ from . import synth  # noqa: F401
 from ._lib import RdfError, library_path  # noqa: F401
 from .decision_tree import (DecisionForest, DecisionTree, DecisionTreeEvaluator,  # noqa: F401
                             DecisionTreeTrainer, LayeredDecisionForest)
-from .device import DeviceArray, HipRuntime, device_ptr, get_runtime, set_runtime, to_device  # noqa: F401
+from .device import DeviceArray, HipRuntime, device_ptr, get_runtime, host_mapped_array, set_runtime, to_device  # noqa: F401
 from .engine.buffer import GpuBuffer  # noqa: F401
 from .host_stream import HostFramesEvaluator  # noqa: F401
 from .pipeline import HandPipeline  # noqa: F401
@@ -21,4 +21,4 @@ from .util import MAX_UINT16  # noqa: F401
 __all__ = ["DecisionTree", "DecisionForest", "LayeredDecisionForest", "DecisionTreeEvaluator", "DecisionTreeTrainer",
            "GpuBuffer", "HandPipeline", "HostFramesEvaluator",
            "DeviceArray", "HipRuntime", "MAX_UINT16", "RdfError", "device_ptr", "get_runtime", "set_runtime",
-           "to_device", "library_path", "synth"]
+           "to_device", "host_mapped_array", "library_path", "synth"]

@@ -40,6 +40,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <map>
@@ -1388,10 +1389,29 @@ typedef std::atomic<int> Knob;
 Knob g_lds_budget{0};
 Knob g_block_threads{0};
 
-int env_int(const char *name, int dflt)
+// The RDF_* environment is read ONCE per variable (the first call that looks at it; thread-safe function-local statics): a
+// launch used to pay ten getenv scans of the environment, microseconds on the critical path of a sync-per-frame live loop.
+// The rdf_set_* knobs are the way to change a choice at run time.
+struct EnvVal {
+    bool set;
+    int val;
+};
+inline EnvVal read_env(const char *name)
 {
     const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
+    const bool set = v && *v;
+    return {set, set ? atoi(v) : 0};
+}
+#define env_int(name, dflt) ([&]() -> int { static const EnvVal e_ = read_env(name); return e_.set ? e_.val : (dflt); }())
+
+// C-side cost of a call (rdf_debug_host_overhead): nanoseconds eval_common spends before it hands the launch to the HIP
+// runtime, and inside the runtime's launch call
+std::atomic<unsigned long long> g_host_ns_plan{0}, g_host_ns_launch{0}, g_host_calls{0};
+inline unsigned long long now_ns()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec;
 }
 
 int lds_budget(int block)
@@ -1405,19 +1425,26 @@ int lds_budget(int block)
 }
 
 struct DeviceInfo {
-    int cus = 0;
+    int cus = 0, dev = 0;
     bool ok = false;
 };
+
+std::atomic<int> g_device_cus[64];      // compute units per device ordinal, asked once (0: not yet)
 
 int device_info(DeviceInfo *out)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    int cus = 0;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return (int)e;
-    out->cus = cus > 0 ? cus : 256;
+    int cus = (dev >= 0 && dev < 64) ? g_device_cus[dev].load(std::memory_order_relaxed) : 0;
+    if (cus == 0) {
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return (int)e;
+        cus = cus > 0 ? cus : 256;
+        if (dev >= 0 && dev < 64) g_device_cus[dev].store(cus, std::memory_order_relaxed);
+    }
+    out->cus = cus;
+    out->dev = dev;
     out->ok = true;
     return 0;
 }
@@ -1436,8 +1463,11 @@ int sched_mode()
 {
     int mode = g_sched_mode;
     if (mode < 0) {
-        const char *v = getenv("RDF_SCHED");
-        mode = (v && strcmp(v, "static") == 0) ? 0 : (v && strcmp(v, "tile") == 0) ? 2 : 1;
+        static const int from_env = []() {
+            const char *v = getenv("RDF_SCHED");
+            return (v && strcmp(v, "static") == 0) ? 0 : (v && strcmp(v, "tile") == 0) ? 2 : 1;
+        }();
+        mode = from_env;
     }
     return mode;
 }
@@ -1554,7 +1584,7 @@ int launch_one(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
             hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) return (int)e;
         }
-        if (!tile_at_lds_zero(kp)) return RDF_ERR_NO_DEVICE;
+        if (!tile_at_lds_zero(kp)) return RDF_ERR_BUILD;
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, BLOCK, (size_t)lds_bytes) != hipSuccess || n < 1)
             n = 1;
@@ -1595,7 +1625,7 @@ int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st
             hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) return (int)e;
         }
-        if (!tile_at_lds_zero(kp)) return RDF_ERR_NO_DEVICE;
+        if (!tile_at_lds_zero(kp)) return RDF_ERR_BUILD;
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kBlock, (size_t)lds_bytes) != hipSuccess || n < 1) n = 1;
         per_cu = n;
@@ -1718,6 +1748,8 @@ int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void 
         n_classes < 0 || r < 1)
         return RDF_ERR_BAD_ARG;
     if ((long long)n_img * dim_x * dim_y >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
+    // (a far probe's byte offset is one 24-bit multiply-add, TileCtx: y * 2W + 2x with y < 2^24 and 2W < 2^24)
+    if (dim_x >= (1 << 23) || dim_y >= (1 << 24)) return RDF_ERR_TOO_LARGE;
     const long long total = (long long)n_img * (dim_x / r) * (dim_y / r);
     if (total == 0) return 1; // nothing to do
     if (!depth || !labels) return RDF_ERR_NULL_PTR;
@@ -1771,6 +1803,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
                 int filter_class, uint16_t *labels_out, int r, float s, int keep_if_no_leaf,
                 unsigned long long *stats, void *stream, int fill_untouched = 0, Plan *plan_only = nullptr, bool allow_tw = true)
 {
+    const unsigned long long t_entry = now_ns();
     int rc = check_common(depth, n_img, dim_x, dim_y, forest, n_trees, max_depth, n_classes, labels_out, r);
     if (rc == 1) {
         if (plan_only) plan_only->empty = true;
@@ -1968,17 +2001,24 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int cus = usable_cus(st, di.cus);   // a CU-masked stream holds fewer persistent workgroups
+    const unsigned long long t_launch = now_ns();
     if (tw) {
         EvalArgsN<1> ka;
         ka.l[0] = a;
-        return a.C <= 4 ? launch_multi<4, 1, true>(ka, lds_bytes, cus, st) : launch_multi<8, 1, true>(ka, lds_bytes, cus, st);
+        rc = a.C <= 4 ? launch_multi<4, 1, true>(ka, lds_bytes, cus, st) : launch_multi<8, 1, true>(ka, lds_bytes, cus, st);
+    } else if (stats) {   // (reference layout, 256 threads: eval_common chose both)
+        rc = launch_one<256, false, 4, true, 4, false>(a, lds_bytes, cus, st);
+    } else if (deep_launch) {
+        rc = block == 512 ? launch_deep<512>(compact_launch, a, lds_bytes, cus, st) : launch_deep<256>(compact_launch, a, lds_bytes, cus, st);
+    } else {
+        rc = block == 512 ? launch_block<512>(packed != nullptr, compact_launch, a, lds_bytes, cus, st)
+                          : launch_block<256>(packed != nullptr, compact_launch, a, lds_bytes, cus, st);
     }
-    if (stats)   // (reference layout, 256 threads: eval_common chose both)
-        return launch_one<256, false, 4, true, 4, false>(a, lds_bytes, cus, st);
-    if (deep_launch)
-        return block == 512 ? launch_deep<512>(compact_launch, a, lds_bytes, cus, st) : launch_deep<256>(compact_launch, a, lds_bytes, cus, st);
-    return block == 512 ? launch_block<512>(packed != nullptr, compact_launch, a, lds_bytes, cus, st)
-                        : launch_block<256>(packed != nullptr, compact_launch, a, lds_bytes, cus, st);
+    const unsigned long long t_done = now_ns();
+    g_host_ns_plan.fetch_add(t_launch - t_entry, std::memory_order_relaxed);
+    g_host_ns_launch.fetch_add(t_done - t_launch, std::memory_order_relaxed);
+    g_host_calls.fetch_add(1, std::memory_order_relaxed);
+    return rc;
 }
 
 } // namespace
@@ -2422,6 +2462,18 @@ int rdf_graph_slots_release(unsigned long long capture_id)
     return n;
 }
 
+// measurement hook: what forest launches cost on the host since the last reset -- nanoseconds inside this library before the
+// launch is handed to the HIP runtime (argument checks, LDS plan, queue slot), nanoseconds inside the runtime's launch call,
+// number of launches (a layered run of n layers in one launch counts n plans and no launch: its launch is in rdf_layered_run)
+int rdf_debug_host_overhead(unsigned long long *ns_plan, unsigned long long *ns_launch, unsigned long long *calls, int reset)
+{
+    if (ns_plan) *ns_plan = g_host_ns_plan.load();
+    if (ns_launch) *ns_launch = g_host_ns_launch.load();
+    if (calls) *calls = g_host_calls.load();
+    if (reset) { g_host_ns_plan = 0; g_host_ns_launch = 0; g_host_calls = 0; }
+    return RDF_OK;
+}
+
 // test hook: how many stream slots / graph slots the current device holds at the moment
 int rdf_debug_sched_slots(int *stream_slots_in_use, int *graph_slots_used)
 {
@@ -2506,8 +2558,9 @@ const char *rdf_error_string(int code)
     case RDF_OK: return "ok";
     case RDF_ERR_BAD_ARG: return "rdf: bad argument";
     case RDF_ERR_NULL_PTR: return "rdf: required pointer is NULL";
-    case RDF_ERR_TOO_LARGE: return "rdf: call addresses >= 2^31 pixels, split the batch";
+    case RDF_ERR_TOO_LARGE: return "rdf: call addresses >= 2^31 pixels (or a frame is 2^23 pixels wide / 2^24 high or more), split the batch";
     case RDF_ERR_NO_DEVICE: return "rdf: no usable HIP device";
+    case RDF_ERR_BUILD: return "rdf: this build of the library breaks an assumption of its own kernels (static LDS in a forest kernel); rebuild it";
     default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);

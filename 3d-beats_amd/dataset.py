@@ -85,23 +85,38 @@ class DecisionTreeDatasetConfig:
     def images_shape(self):
         return (self.num_images, self.img_dims[1], self.img_dims[0])
 
+    def _palette(self):
+        """(sorted RGBA keys as uint32, their class ids, id -> RGBA table) built once from id_to_color."""
+        if getattr(self, "_pal", None) is None:
+            ids = np.array(sorted(self.id_to_color), dtype=np.int64)
+            rgba = np.stack([np.asarray(self.id_to_color[int(i)], dtype=np.uint8) for i in ids])
+            keys = np.ascontiguousarray(rgba).view(np.uint32).reshape(-1)
+            order = np.argsort(keys, kind="stable")
+            table = np.zeros((int(ids.max()) + 1, 4), dtype=np.uint8)
+            table[ids] = rgba
+            self._pal = (keys[order], ids[order], table)
+        return self._pal
+
     def convert_colors_to_ids(self, labels_color):
-        ids = np.zeros((self.img_dims[1], self.img_dims[0]), dtype=np.uint16)
-        seen = 0
-        for class_id, color in self.id_to_color.items():
-            m = np.all(labels_color == color, axis=2)
-            ids[m] = class_id
-            seen += int(m.sum())
-        assert seen == self.img_dims[0] * self.img_dims[1], 'every pixel must carry a known label colour'
-        return ids
+        """RGBA label image [H, W, 4] -> class ids [H, W] (decision_tree.py:97-110): every pixel must carry one of the
+        dataset's colours.  One 32-bit key per pixel, looked up in the sorted palette."""
+        keys, ids, _ = self._palette()
+        px = np.ascontiguousarray(labels_color, dtype=np.uint8)
+        assert px.shape == (self.img_dims[1], self.img_dims[0], 4), px.shape
+        k = px.view(np.uint32).reshape(px.shape[0], px.shape[1])
+        at = np.minimum(np.searchsorted(keys, k), keys.size - 1)
+        assert np.array_equal(keys[at], k), 'every pixel must carry a known label colour'
+        return ids[at].astype(np.uint16)
 
     def convert_ids_to_colors(self, labels_ids):
+        """Class ids [N, H, W] -> RGBA [N, H, W, 4] (decision_tree.py:112-122); an id the dataset does not know stays
+        transparent black."""
         n, y, x = labels_ids.shape
         assert (y, x) == (self.img_dims[1], self.img_dims[0])
-        out = np.zeros((n, y, x, 4), dtype=np.uint8)
-        for class_id, color in self.id_to_color.items():
-            out[labels_ids == class_id] = color
-        return out
+        _, _, table = self._palette()
+        ids = np.asarray(labels_ids).astype(np.int64)
+        known = (ids >= 0) & (ids < table.shape[0])
+        return np.where(known[..., None], table[np.where(known, ids, 0)], np.uint8(0)).astype(np.uint8)
 
 
 def write_dataset(dataset_dir, depth, labels, id_to_color):

@@ -49,7 +49,20 @@ class HipRuntime:
     def ptr(self, handle):
         return int(handle.data_ptr())
 
+    def _host_side(self, handle):
+        """Host-mapped storage (alloc_host_mapped) is a pinned CPU tensor: copies to and from it are plain host memory
+        traffic that no stream orders.  Kernels queued on the current stream may still be writing or reading it, so every
+        host-side access waits for that stream first (the reference's `.cu().get()` right after a launch, run_live.py:131,
+        then sees the finished labels, as a device buffer's synchronous copy does)."""
+        if handle.device.type != "cpu":
+            return False
+        self.synchronize()
+        return True
+
     def h2d(self, handle, offset, host_u8):
+        if self._host_side(handle):
+            handle.numpy()[offset:offset + host_u8.size] = host_u8
+            return
         if host_u8.flags.writeable:
             handle[offset:offset + host_u8.size].copy_(self.torch.from_numpy(host_u8), non_blocking=False)
             return
@@ -60,6 +73,8 @@ class HipRuntime:
             handle[offset + a:offset + a + piece.size].copy_(self.torch.from_numpy(piece), non_blocking=False)
 
     def d2h(self, handle, offset, nbytes):
+        if self._host_side(handle):
+            return handle.numpy()[offset:offset + nbytes].copy()
         return handle[offset:offset + nbytes].cpu().numpy()
 
     def as_torch(self, handle, offset, nbytes):
@@ -77,6 +92,7 @@ class HipRuntime:
                        "rdf_fill_u16")
             return
         t = self.torch
+        self._host_side(handle)          # (a host write: nothing queued may still be using the memory)
         view = handle[offset:offset + nbytes]
         if len(set(pattern_u8.tolist())) == 1:
             view.fill_(int(pattern_u8[0]))

@@ -166,6 +166,8 @@ class PeerCopyGather:
         # default stream), so a poll never queues behind a forest launch; values come from a device table (index = value - 1)
         handle = [None]
         mine_ok, why = 1, None
+        import threading
+        self._host_lock = threading.Lock()     # the pinned landing buffer, the poll stream and the value table: one user at a time
         try:
             self._poll_stream = torch.cuda.Stream()
             self._host8 = torch.zeros(max(self.world + 1, 8) * self.n_slots * (self.FLAG_STRIDE // 8), dtype=torch.int64).pin_memory()
@@ -287,6 +289,10 @@ class PeerCopyGather:
     def _value_ptr(self, value):
         """Device address of an int64 that holds `value` (>= 1): the source of a counter update by device-to-device copy."""
         value = int(value)
+        with self._host_lock:
+            return self._value_ptr_locked(value)
+
+    def _value_ptr_locked(self, value):
         if not (self._vals_base < value <= self._vals_base + self._vals.numel()):
             self._old_vals = (self._old_vals + [self._vals])[-2:]      # (copies in flight may still read the old table)
             self._vals_base = ((value - 1) // 65536) * 65536
@@ -302,11 +308,14 @@ class PeerCopyGather:
 
     def _peek(self, ptr, n_words):
         """n_words int64 at device address `ptr`, read now (own stream), as a list."""
-        st = ctypes.c_void_p(self._poll_stream.cuda_stream)
-        rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self._host8.data_ptr()), ctypes.c_void_p(ptr), 8 * n_words, st)
-        _lib.check(self._lib, rc, "rdf_memcpy_device_async (counters)")
-        _lib.check(self._lib, self._lib.rdf_stream_synchronize(st), "rdf_stream_synchronize")
-        return self._host8[:n_words].tolist()
+        # (the producer's wait_free and a consumer thread's wait_ready / ready_counters share the pinned landing buffer and
+        # the poll stream: one reader at a time, the list is made before the next one may overwrite the buffer)
+        with self._host_lock:
+            st = ctypes.c_void_p(self._poll_stream.cuda_stream)
+            rc = self._lib.rdf_memcpy_device_async(ctypes.c_void_p(self._host8.data_ptr()), ctypes.c_void_p(ptr), 8 * n_words, st)
+            _lib.check(self._lib, rc, "rdf_memcpy_device_async (counters)")
+            _lib.check(self._lib, self._lib.rdf_stream_synchronize(st), "rdf_stream_synchronize")
+            return self._host8[:n_words].tolist()
 
     # -- producer side -----------------------------------------------------------------------------
     def push(self, step, src_ptr, nbytes, stream):

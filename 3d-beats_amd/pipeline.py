@@ -107,8 +107,17 @@ class HandPipeline:
         # the recorded forest launches hold tile-queue slots of their own: given back when the replay object is dropped
         # (the graph goes with it), so that captures over a process's lifetime never run out of them
         if named:
-            lib, cid = self._lib, int(cap_id.value)
-            replay.release = weakref.finalize(replay, lambda g=graph: (g.reset(), lib.rdf_graph_slots_release(cid)))
+            lib, cid, dev = self._lib, int(cap_id.value), torch.cuda.current_device()
+
+            def _release(g=graph):
+                # the last replay may still be running, on whatever stream it was launched on: its tile-queue slots must
+                # not reach the next capture while its workgroups pull from them (two launches sharing a queue skip tiles);
+                # and the slots are keyed by device, so the device of the capture is made current for the release
+                with torch.cuda.device(dev):
+                    torch.cuda.synchronize(dev)
+                    g.reset()
+                    lib.rdf_graph_slots_release(cid)
+            replay.release = weakref.finalize(replay, _release)
         return replay
 
     def _read(self):

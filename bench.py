@@ -90,6 +90,8 @@ def parse():
                     "(one per shader engine = 32) to RCCL's kernels; -1: 32 with the rccl gather, 0 otherwise (DESIGN.md section 6)")
     ap.add_argument("--fail-ipc-open-on-rank", type=int, default=None, help="test hook: that rank behaves as if it could not map "
                     "rank 0's receive buffer (the run must fall back to the RCCL gather and say why)")
+    ap.add_argument("--force-distributed", action="store_true", help="take the N>1 code path (communicator, gather modes, CU-masked "
+                    "stream, checksums, `distributed` block, config 5 on all ranks) even with ONE rank: puts the RCCL path on a one-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
                     "rehearse the control flow with several ranks on one GPU)")
     return ap.parse_args()
@@ -195,12 +197,14 @@ def roofline_for(leg, key, live, kernel_ms, alg_bytes):
 
 
 def main():
+    t_main = time.perf_counter()
     a = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL, peer-mapped buffers); before HIP starts
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    full_run = world == 1 and a.leg is None and not a.headline_only
+    multi = world > 1 or a.force_distributed        # the distributed code path (one rank too, with --force-distributed)
+    full_run = not multi and a.leg is None and not a.headline_only
 
     # ---- counters first: the child passes must run before this process touches the GPU ----
     live = None
@@ -221,7 +225,7 @@ def main():
         a.gpus = world
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
@@ -238,7 +242,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -381,41 +385,65 @@ def main():
                     check = "MISMATCH"
         pix = world * F5 * H5 * W5
         # the same shard with every rank's kernel writing its labels straight into rank 0's IPC-mapped ring (no transfer stage:
-        # DESIGN.md section 6, third way); collective, and whatever goes wrong on any rank becomes a field
-        direct = None
-        try:
-            pg5 = dmod.PeerCopyGather(world, rank, F5 * H5 * W5 * 2)
-            if pg5.ok:
-                pe5 = dmod.PeerCopyForestEvaluator(ev, forest5, F5, (H5, W5), pg5, direct_stores=True)
+        # DESIGN.md section 6, third way).  Collective: a rank on which something raises stops doing work but still walks
+        # through every collective below (as `timed` does), the outcome is agreed by an all-gather, and the ring is closed
+        # on every path -- peers unmap, barrier, rank 0 frees.
+        def direct_stores_leg():
+            pg5 = dmod.PeerCopyGather(world, rank, F5 * H5 * W5 * 2)      # (every rank leaves the constructor with the same `ok`)
+            if not pg5.ok:
+                return {"unavailable": "; ".join(f"rank {g}: {why}" for g, why in (pg5.errors or {}).items())}
+            failure = []
+
+            def guarded(fn):
+                if failure:
+                    return None
+                try:
+                    return fn()
+                except Exception as e:   # noqa: BLE001
+                    failure.append(f"rank {rank}: {type(e).__name__}: {e}"[:300])
+                    return None
+            try:
+                pe5 = guarded(lambda: dmod.PeerCopyForestEvaluator(ev, forest5, F5, (H5, W5), pg5, direct_stores=True))
                 for _ in range(warmup):
-                    pe5.step(depth5, None)
-                pe5.drain()
+                    guarded(lambda: pe5.step(depth5, None))
+                guarded(lambda: pe5.drain())
                 sync_all()
                 t0 = time.perf_counter()
                 for _ in range(steps):
-                    pe5.step(depth5, None)
-                pe5.drain()
+                    guarded(lambda: pe5.step(depth5, None))
+                guarded(lambda: pe5.drain())
                 sync_all()
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 t_direct = float(t.item())
-                chk, got5 = None, None
+                chk = None
                 if rank == 0:
-                    chk = "ok"
-                    got5 = pe5.result()
-                    for g in range(world):
-                        p64 = got5[g * F5:(g + 1) * F5].reshape(-1).to(torch.int64)
-                        c2_ = torch.stack([p64.sum(), (p64 * (torch.arange(p64.numel(), device=p64.device) % 8191)).sum()])
-                        if not torch.equal(c2_, allsums[g]):
-                            chk = "MISMATCH"
-                direct = {"value": round(pix * steps / t_direct / 1e6, 2), "ms_per_step": round(t_direct / steps * 1e3, 4),
-                          "gather_check": chk}
+                    def verify():
+                        got5 = pe5.result()
+                        for g in range(world):
+                            p64 = got5[g * F5:(g + 1) * F5].reshape(-1).to(torch.int64)
+                            c2_ = torch.stack([p64.sum(), (p64 * (torch.arange(p64.numel(), device=p64.device) % 8191)).sum()])
+                            if not torch.equal(c2_, allsums[g]):
+                                return "MISMATCH"
+                        return "ok"
+                    chk = guarded(verify)
+                why = [None] * world
+                dist.all_gather_object(why, failure[0] if failure else None)
+                if any(why):
+                    return {"error": "; ".join(w for w in why if w)}
+                return {"value": round(pix * steps / t_direct / 1e6, 2), "ms_per_step": round(t_direct / steps * 1e3, 4), "gather_check": chk}
+            finally:
+                pe5 = None
                 dist.barrier()
-                pg5.close()
-                del pe5, got5
-            else:
-                direct = {"unavailable": "; ".join(f"rank {g}: {why}" for g, why in (pg5.errors or {}).items())}
-        except Exception as e:   # noqa: BLE001
+                if rank != 0:
+                    pg5.close()
+                dist.barrier()
+                if rank == 0:
+                    pg5.close()
+
+        try:
+            direct = direct_stores_leg()
+        except Exception as e:   # noqa: BLE001 -- (a failing collective itself: nothing more can be agreed on)
             direct = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:300]}
         res = {"value": round(pix * steps / t_gather / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(t_gather / steps * 1e3, 4),
                "value_kernel_only": round(pix * steps / t_kernel / 1e6, 2), "kernel_only_ms": round(t_kernel / steps * 1e3, 4),
@@ -471,14 +499,14 @@ def main():
     # N>1: one launch per step; the gather of step s overlaps the evaluation of step s+1 (two label buffers);
     # --chunks C > 0 selects the in-step pipeline instead (C launches, gather of chunk c overlaps chunk c+1)
     chunks = a.chunks or 1
-    overlapped = world > 1 and a.chunks == 0
+    overlapped = multi and a.chunks == 0
     sharded = dmod.ShardedForestEvaluator(ev, forest, F, (H, W), n_chunks=chunks)
     ring = [labels, rdf.DeviceArray((F, H, W), np.uint16).fill(65535)] if overlapped else None
 
     # N>1, default: peer copies over xGMI by the copy engines (RCCL carries only the control plane); needs HIP IPC
     # between the ranks' processes, falls back to the RCCL gather if any rank cannot map rank 0's buffer
     peer, pg, peer_direct, pg_d, notes = None, None, None, None, {}      # notes: what was unavailable on this run and why (goes on the N > 1 line)
-    if world > 1 and a.chunks == 0 and a.gather in ("auto", "p2p", "both"):
+    if multi and a.chunks == 0 and a.gather in ("auto", "p2p", "both"):
         pg = dmod.PeerCopyGather(world, rank, F * H * W * 2, _fail_open_on_rank=a.fail_ipc_open_on_rank)
         if pg.ok:
             peer = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg)
@@ -552,7 +580,7 @@ def main():
             kms = [evs.elapsed_ms(2 * i, 2 * i + 1) for i in range(a.steps)]
             evs.destroy()
         failed = None
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -594,7 +622,7 @@ def main():
         step = (lambda: sharded.step_overlapped(depth, ring)) if overlapped else (lambda: sharded.step(depth, labels))
         return (step, sharded.drain, st, reserve if st is not None else 0, sharded.result, False)
 
-    if world == 1:
+    if not multi:
         modes["none"] = (lambda: sharded.step(depth, labels), sharded.drain, None, 0, None, False)
     else:
         if peer is not None and a.gather != "rccl":
@@ -610,7 +638,7 @@ def main():
     while queue:
         name, (step, drain, st, reserve, result_fn, from_peer) = queue.pop(0)
         elapsed, kms, failed = timed(step, drain, st)
-        if failed is None and world > 1:
+        if failed is None and multi:
             try:
                 check = gather_check(result_fn, from_peer)
             except Exception as e:   # noqa: BLE001 -- (every rank has left the collectives of gather_check by now or none has)
@@ -648,12 +676,12 @@ def main():
         intact = [n for n in results if verdicts[0].get(n) == "ok"] or list(results)
         primary = min(intact, key=lambda n: results[n]["elapsed"])
     elapsed, kern_ms = results[primary]["elapsed"], results[primary]["kern_ms"]
-    if world == 1:
+    if not multi:
         assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"
 
     # ---- the kernel alone on every rank (no gather enqueued): Mpix/s with and without the gather, SURVEY 8(e) ----
     kern_only = None
-    if world > 1:
+    if multi:
         ek = Events(rt, 2)
         sync_all()
         ek.record(0)
@@ -675,13 +703,13 @@ def main():
         print(json.dumps({"leg": "headline", "topology": a.topology, "kernel_ms": round(kern_avg_ms, 4), "value": round(value, 2), "tune": tune}), flush=True)
         return
 
-    gather_mode = None if world == 1 else primary
+    gather_mode = None if not multi else primary
     # N = 1: `value` is the MEDIAN of the K per-step hipEvent times (SURVEY 8d's protocol), the K steps between the two
     # barriers -- what the bench contract brackets -- are beside it as value_mean / ms_per_step_mean (they differ by a few
     # tenths of a per cent).  N > 1: `value` is the bracketed K steps, MAX over ranks, gather included; a per-step median
     # would leave the gather out, so it is reported for this rank's launches only (ms_per_step_median).
     mean_ms = elapsed / a.steps * 1e3
-    if world == 1:
+    if not multi:
         head = {"value": round(F * H * W / kern_med_ms / 1e3, 2), "ms_per_step": round(kern_med_ms, 4),
                 "value_mean": round(value, 2), "ms_per_step_mean": round(mean_ms, 4), "value_is": "median of the per-step times"}
     else:
@@ -697,12 +725,12 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", **head,
         "config": {"workload": f"{F} x {W}x{H} depth frames per GPU per step (config 4 shard = config 2 frame x {F}; "
                                f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
-                               + (f"labels gathered to rank 0 ({gather_mode}; control plane {a.backend}) inside the timed region" if world > 1 else "1 GPU"),
+                               + (f"labels gathered to rank 0 ({gather_mode}; control plane {a.backend}) inside the timed region" if multi else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
                    "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
                    "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": results[primary]["reserve"],
                    "gather": gather_mode,
-                   "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if world > 1 else None)),
+                   "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if multi else None)),
                    "sharding": f"frames x{world}, forest replicated", "gather_check": results[primary]["gather_check"],
                    "deep_level_table": tune},
         # the same rate counted over the pixels the forest really evaluates (this rank's batch: half of it is live-like
@@ -710,7 +738,7 @@ def main():
         "value_valid_pixels": round(out_value_tmp * valid_px / (F * H * W), 2),
         "valid_pixel_share": round(valid_px / (F * H * W), 4),
     }
-    if world > 1:
+    if multi:
         # what a driver needs to verify the run: N ranks of ONE RCCL communicator on N distinct devices
         uuid = str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", f"index-{dev_index}"))
         ids = [None] * world
@@ -1055,8 +1083,10 @@ def main():
             out["counter_passes"] = {leg: {"seconds": v["seconds"], "log": v["log"]} for leg, v in live.items()}
 
     if rank == 0:
+        if multi:
+            out["distributed"]["total_seconds"] = round(time.perf_counter() - t_main, 1)    # this process, start to line
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         for ring in (pg, pg_d):                 # unmap on the peers before rank 0 frees the buffer
             if ring is not None and ring.ok:        # (`ok` is agreed on every rank: the barrier below is entered by all or none)

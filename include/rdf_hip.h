@@ -34,8 +34,10 @@ extern "C" {
 #define RDF_OK 0
 #define RDF_ERR_BAD_ARG (-1)     /* negative size, labels_reduce < 1, max_depth outside [0,30] ... */
 #define RDF_ERR_NULL_PTR (-2)    /* a required pointer is NULL */
-#define RDF_ERR_TOO_LARGE (-3)   /* one call addresses >= 2^31 depth pixels; split the batch */
+#define RDF_ERR_TOO_LARGE (-3)   /* one call addresses >= 2^31 depth pixels (split the batch), or dim_x >= 2^23 / dim_y >= 2^24 */
 #define RDF_ERR_NO_DEVICE (-4)   /* no HIP device / not a gfx950 code object */
+#define RDF_ERR_BUILD (-5)       /* the library was built in a way its own kernels do not allow (a forest kernel got static LDS:
+                                    its depth tile must sit at LDS address 0) */
 
 /*
  * Forest evaluation.  Replaces `evaluate_image_using_forest`
@@ -134,6 +136,13 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
  * trailer {1 + deepest level holding a node that needs the exact record, nodes of the last level that are not plain
  * two-leaf nodes}.  Launches walk the levels no cache holds from it, a third of the line fetches per walk
  * (rdf_set_deep_from).  `packed` must be 128-byte aligned.
+ * Footprint, per heap slot (2^max_depth slots per tree): 16 B hot + 32 B exact + 8 B x classes (padded to 4) of leaf PDFs,
+ * + 32 B (half a 64-byte record per slot of the deepest level; up to four classes) + ~37 B of deep blocks (128 B per
+ * seven nodes plus 128 B per node of level D - 2): a T4/D20/C4 forest (240 MiB as .npy) packs into 64 + 128 + 128 + 128 +
+ * 146 MiB = 594 MiB, T8/D22/C4 (1.9 GiB) into 4.6 GiB -- 2.5 x the model, 1.6 % of one MI355X's HBM; every table exists so
+ * that a walk touches ONE cache line where the .npy layout touches two or three.  The exact table stays dense although
+ * almost no forest has a node that needs it: the size must follow from (trees, depth, classes) alone, before the forest
+ * is seen.
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
@@ -355,8 +364,13 @@ int rdf_debug_floor_i32(const float *in, int32_t *out, size_t n, void *stream);
 /* Test hook: out[i] = num[i] / den[i] as the kernels compute it (IEEE fp32 divide). */
 int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, void *stream);
 
+/* Measurement hook: host-side cost of the forest launches since the last reset: nanoseconds spent inside this library before
+ * a launch is handed to the HIP runtime, nanoseconds inside the runtime's launch call, launches counted (all nullable). */
+int rdf_debug_host_overhead(unsigned long long *ns_plan, unsigned long long *ns_launch, unsigned long long *calls, int reset);
+
 /* Tuning knobs (process-wide atomics, each read once per call; 0 restores the default).  Not part of the reference
- * surface. */
+ * surface.  The RDF_* environment variables that name the same choices are read once per process, at the first call that
+ * looks at them; a knob set through these functions wins. */
 void rdf_set_lds_budget_bytes(int bytes);
 void rdf_set_block_threads(int threads); /* 256 or 512; anything else: the default (512 for launches that fill the chip) */
 void rdf_set_compaction(int mode);       /* -1 (default): filtered launches list their pixels first; 0: never */

@@ -6,6 +6,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -119,3 +120,30 @@ def test_a_rank_that_cannot_map_the_ring_turns_the_run_to_the_rccl_gather(tmp_pa
     assert d["n_gpus"] == 2 and d["config"]["gather"] == "rccl gather" and d["config"]["gather_check"] == "ok" and d["value"] > 0
     assert list(dd["gather_modes"]) == ["rccl gather"]
     assert dd["unavailable"]["p2p"].startswith("unavailable: rank 1: hipIpcOpenMemHandle")
+
+
+@pytest.mark.gpu
+def test_the_rccl_path_runs_on_one_rank(tmp_path):
+    """The N>1 branch of bench.py under the REAL backend (nccl = RCCL) with one rank (--force-distributed): communicator
+    init with a device id, the CU-masked compute stream, dist.gather on the side stream, the peer ring (rank 0 is its own
+    peer), the kernels' direct stores into it, checksum verification, the `distributed` block and config 5 on all ranks.  It
+    proves nothing about xGMI -- the box has one GPU and RCCL refuses two ranks on one device -- but no line of the path the
+    driver's 8-GPU run takes is executed there for the first time."""
+    env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--frames", "8", "--depth", "12", "--backend", "nccl", "--gather", "auto", "--force-distributed",
+           "--cfg5-frames", "2", "--cfg5-trees", "3", "--cfg5-depth", "12"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    dd = d["distributed"]
+    assert d["n_gpus"] == 1 and dd["backend"] == "nccl" and dd["rccl_ranks"] == 1 and dd["distinct_devices"] == 1
+    assert set(dd["gather_modes"]) == {"p2p copy engines", "p2p direct stores", "rccl gather"}
+    assert all(m["gather_check"] == "ok" for m in dd["gather_modes"].values()), dd["gather_modes"]
+    assert dd["gather_modes"]["rccl gather"]["cus_left_to_rccl"] == 32          # the CU-masked stream was had
+    assert dd["unavailable"] == {} and d["config"]["gather_check"] == "ok" and d["value"] > 0
+    c5 = d["cfg5_all_ranks"]
+    assert c5["gather_check"] == "ok" and c5["p2p_direct_stores"]["gather_check"] == "ok"
+    assert d["distributed"].get("total_seconds", 0) <= time.time() - t0 + 1

@@ -994,8 +994,19 @@ def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_o
     gpu_runtime.synchronize()
     slots = trees << levels
     trailer = slots * (48 + 32) + (trees << (levels - 1)) * 64
-    assert packed.nbytes == trailer + 64
+    assert packed.nbytes >= trailer + 64           # (the deep blocks follow, 128-byte aligned)
     unusable, in_use = (int(x) for x in packed.get()[trailer:trailer + 8].view(np.uint32))
+    # the deep blocks' trailer says the same in its own words: 1 + the deepest level with a node that needs the exact record,
+    # and the nodes of the last level that are not plain two-leaf nodes
+    if levels >= 5:
+        deep_at = (trailer + 64 + 127) & ~127
+        r0 = levels - 2
+        deep_lines = trees * (((1 << r0) - (1 << (r0 % 3))) // 7) + (trees << r0)
+        assert packed.nbytes == deep_at + (deep_lines + 2) * 128
+        exact_below, last_bad = (int(x) for x in packed.get()[deep_at + (deep_lines + 1) * 128:][:8].view(np.uint32))
+        assert exact_below == (levels if spoil == "huge_numerator" else 0) and last_bad == unusable
+    else:
+        assert packed.nbytes == trailer + 64
     assert unusable == (1 if spoil in ("continue_flag", "huge_numerator") else 0)
     # word 1: the deepest nodes some parent continues to (the default takes the table from half of the level on)
     to_child = f_np[:, first // 2:first, 5:7].reshape(trees, -1)

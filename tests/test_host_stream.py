@@ -94,3 +94,35 @@ def test_layered_run_writes_its_composite_into_host_memory(rdf, gpu_runtime, ora
         lf.run(dbuf, out, 1.0)
         gpu_runtime.synchronize()
         assert np.array_equal(out.host, comp[0]), (fused, int((out.host != comp[0]).sum()))
+
+
+def test_host_mapped_get_set_and_fill_wait_for_the_stream(rdf, gpu_runtime, oracle):
+    """The reference idiom `labels.cu().get()` right after a launch (run_live.py:131) on a host-mapped buffer: get(), set()
+    and byte fills are host-memory accesses, so they wait for the stream that may still be writing or reading the memory --
+    no manual synchronize."""
+    synth = rdf.synth
+    h, w = 480, 848
+    forest_np = synth.forest(4, 16, 4, "full", 11)
+    forest = rdf.DecisionForest.from_numpy(forest_np)
+    frames = synth.frames(["dense", "dense", "live", "dense"], 4300, h, w)
+    want = np.full(frames.shape, 65535, np.uint16)
+    oracle.eval_forest(frames, forest_np, want)
+    ev = rdf.DecisionTreeEvaluator()
+    depth = rdf.to_device(frames)
+    labels, host = rdf.host_mapped_array(frames.shape, np.uint16)
+    for rep in range(3):
+        labels.fill(65535)                      # (a u16 fill is a kernel on the stream)
+        ev.get_labels_forest(forest, depth, labels)
+        got = labels.get()                      # no synchronize in between
+        assert np.array_equal(got, want), (rep, int((got != want).sum()))
+    # set() right behind a launch that READS the memory: a host-mapped DEPTH buffer
+    dmap, _ = rdf.host_mapped_array(frames.shape, np.uint16)
+    dmap.set(frames)
+    out = rdf.DeviceArray(frames.shape, np.uint16).fill(65535)
+    ev.get_labels_forest(forest, dmap, out)
+    dmap.set(np.zeros_like(frames))             # must not reach the kernel that is still reading the frames
+    assert np.array_equal(out.get(), want)
+    # a byte fill (not a u16 pattern) behind a launch that writes
+    lab8, host8 = rdf.host_mapped_array((16,), np.uint8)
+    lab8.fill(np.uint8(3))
+    assert (host8 == 3).all()
