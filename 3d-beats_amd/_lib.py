@@ -26,6 +26,8 @@ SIGNATURES = {
                                       _c_int, _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "rdf_forest_packed_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "rdf_forest_pack": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "rdf_eval_forest_packed_stats": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
+                                              _c_int, _c_void_p, _c_void_p]),
     "rdf_forest_set_deep_from": (_c_int, [_c_void_p, _c_int]),
     "rdf_forest_tune": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                                  _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),

@@ -178,6 +178,7 @@ struct EvalArgs {
     const uint16_t *filter;
     uint16_t *labels;
     unsigned long long *stats;
+    int stats_wide;        // stats holds 8 counters (rdf_eval_forest_packed_stats), not 3
     unsigned int *sched;   // queue slot, or nullptr for static round-robin tiles
     uint32_t n_tiles;      // n_img * tiles_x * tiles_y
     uint32_t tiles_x;      // ceil(Wl / 64)
@@ -398,7 +399,30 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
         }
     }
     if (tid == 0) s_tile[2] = s_tile[3] = 0u;   // (made visible by the first tile's barrier)
-    unsigned long long st_px = 0, st_lv = 0, st_lf = 0;
+    // (STATS) per-lane visit counters: pixels, node records read, leaves reached; and what a launch with THIS geometry needs
+    // from the vector memory pipeline at the least: node records read from LDS, and 128-byte lines touched by the loads that
+    // serve walking slots -- records and leaf rows from global memory, far probes that load, deep blocks -- counted per wave
+    // instruction with neighbouring lanes on one line merged, as the L1 merges them (tools/roofline.py: useful accesses)
+    uint32_t st_px = 0, st_lv = 0, st_lf = 0, st_lds = 0, st_rec = 0, st_leaf = 0, st_far = 0, st_blk = 0;
+    // lanes of this wave instruction that touch a line their left neighbour does not touch as well
+    // a probe of a walking slot that leaves the staged tile and lies inside the image loads from global memory (TileCtx)
+    auto far_lines = [&](const TileCtx &c, uint32_t cx2, uint32_t cy, bool walking, uint32_t img_byte_off) -> uint32_t {
+        const bool in_tile = cx2 < c.tw2 && cy < c.th;
+        const uint32_t x2 = cx2 + c.tx0_2, y = cy + c.ty0;
+        const bool loads = walking && !in_tile && x2 < c.W2 && y < c.H;
+        const uint32_t line = (img_byte_off + __umul24(y, c.W2) + x2) >> 7;
+        const uint32_t prev = (uint32_t)__shfl_up((int)line, 1);
+        const unsigned long long m = __ballot(loads);        // (a lane the pixel loop has switched off counts as idle)
+        const bool prev_loads = lane > 0 && ((m >> (lane - 1)) & 1ull) != 0ull;
+        return (loads && (!prev_loads || prev != line)) ? 1u : 0u;
+    };
+    auto lines_of = [&](bool active, uint32_t byte_off) -> uint32_t {
+        const uint32_t line = byte_off >> 7;
+        const uint32_t prev = (uint32_t)__shfl_up((int)line, 1);
+        const unsigned long long m = __ballot(active);
+        const bool prev_active = lane > 0 && ((m >> (lane - 1)) & 1ull) != 0ull;
+        return (active && (!prev_active || prev != line)) ? 1u : 0u;
+    };
     const char *depth_b = reinterpret_cast<const char *>(a.depth);
     const int tw = a.tw, th = a.th, twp = a.twp;
     uint32_t static_tile = block_id;
@@ -590,6 +614,8 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
         // adds the PDF of the leaf a finished walk (state word hk, see the level loop) reached in tree `tree` to pdf[],
         // classes c0 .. c0 + CMAX - 1; false when the walk reached no leaf (tree_eval.cu:95-128: level D-1 says "continue")
         auto add_leaf_pdf = [&](uint32_t hk, int tree, int c0, float (&pdf)[CMAX]) -> bool {
+            if (STATS && c0 == 0)       // (the reference layout's leaf sits inside its node's record: another line more often than not)
+                st_leaf += lines_of((int)hk < 0 && hk != kIdle, PACKED ? (hk & ~kDone) * (uint32_t)(a.cpad * 4) : ((hk & ~kDone) >> 1) * (uint32_t)a.E * 4u);
             if (!((int)hk < 0 && hk != kIdle)) return false;
             const uint32_t leaf = (hk & ~kDone) - 2u;   // (node - 1) * 2 + side
             if (PACKED) {
@@ -707,6 +733,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             for (int k = 0; k < GROUP; ++k) {
                                 const uint32_t tk = (uint32_t)min(kb + k, a.T - 1);   // wave-uniform
                                 n[k] = decode_node(lds_nodes[tk * lds_pitch + hn[k]]);
+                                if (STATS && c0 == 0) st_lds += (int)h[k] > 0 ? 1u : 0u;
                             }
                         } else if (PACKED) {
 #pragma unroll
@@ -714,12 +741,14 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                 const int tk = min(kb + k, a.T - 1);
                                 const char *base = reinterpret_cast<const char *>(a.packed16 + ((size_t)tk << a.D));
                                 n[k] = decode_node(*reinterpret_cast<const uint4 *>(base + hn[k] * 16u));
+                                if (STATS && c0 == 0) st_rec += lines_of((int)h[k] > 0, hn[k] * 16u);
                             }
                         } else {
 #pragma unroll
                             for (int k = 0; k < GROUP; ++k) {
                                 const int tk = min(kb + k, a.T - 1);
                                 const float *p = a.forest + ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
+                                if (STATS && c0 == 0) st_rec += lines_of((int)h[k] > 0, (hn[k] - 1u) * (uint32_t)a.E * 4u);
                                 const f4u uv = *reinterpret_cast<const f4u *>(p);
                                 const f3u tf = *reinterpret_cast<const f3u *>(p + 4);
                                 n[k].ax = a.s * uv.x; n[k].ay = a.s * uv.y; n[k].bx = a.s * uv.z; n[k].by = a.s * uv.w;
@@ -796,6 +825,10 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                         for (int k = 0; k < GROUP; ++k) {
                             qu[k] = tprobe_issue(pc, ux[k], uy[k]);
                             qv[k] = tprobe_issue(pc, vx[k], vy[k]);
+                            if (STATS && c0 == 0) {
+                                st_far += far_lines(pc, ux[k], uy[k], (int)h[k] > 0, img_boff);
+                                st_far += far_lines(pc, vx[k], vy[k], (int)h[k] > 0, img_boff);
+                            }
                         }
 
                         // ---- decide (tree_eval.cu:107-121) ----
@@ -841,6 +874,11 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                     const f2 tv = __builtin_elementwise_fma(nv, r2, m2);
                                     qu[w] = tprobe_issue(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky);
                                     qv[w] = tprobe_issue(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky);
+                                    if (STATS && c0 == 0) {
+                                        st_lv += (int)hk[w] > 0 ? 1u : 0u;
+                                        st_far += far_lines(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky, (int)hk[w] > 0, img_boff);
+                                        st_far += far_lines(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky, (int)hk[w] > 0, img_boff);
+                                    }
                                 }
 #pragma unroll
                                 for (int w = 0; w < W; ++w) {
@@ -862,6 +900,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                     const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.deep) + base_at + off);
 #pragma unroll
                                     for (int i = 0; i < 7; ++i) q[i][w] = bp[i];
+                                    if (STATS && c0 == 0) st_blk += (int)hk[w] > 0 ? 1u : 0u;     // (a block is a line of its own)
                                 }
                                 // (issued together -- the line is filled once -- before anything is decoded)
 #pragma unroll
@@ -940,6 +979,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 #pragma unroll
                                 for (int w = 0; w < W; ++w) {
                                     const int tk = min(kb + k0 + w, a.T - 1);
+                                    if (STATS && c0 == 0) st_leaf += lines_of(early[w], (hk[w] & ~kDone) * (uint32_t)(a.cpad * 4));
                                     // 16-byte rows: (((tree << D) + node) * 2 + side) * (cpad / 4), node * 2 + side = h & ~kDone (add_leaf_pdf)
                                     const uint4 *row = reinterpret_cast<const uint4 *>(a.packed_pdf) +
                                                        (early[w] ? (((size_t)tk << (a.D + 1)) + (hk[w] & ~kDone)) * (size_t)(a.cpad >> 2) : (size_t)0);
@@ -966,6 +1006,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 #pragma unroll
                             for (int w = 0; w < W; ++w) {
                                 if (have[w] || early[w]) {
+                                    if (STATS && c0 == 0) st_lf++;
                                     pdf[0] = pdf[0] + __uint_as_float(p0[w].x); pdf[1] = pdf[1] + __uint_as_float(p0[w].y);
                                     pdf[2] = pdf[2] + __uint_as_float(p0[w].z); pdf[3] = pdf[3] + __uint_as_float(p0[w].w);
                                     if constexpr (CMAX == 8) {
@@ -1024,7 +1065,13 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                 const f2 tv = __builtin_elementwise_fma(nv, r2, m2);
                                 const TileProbe qu = tprobe_issue(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky);
                                 const TileProbe qv = tprobe_issue(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky);
-                                if (STATS && c0 == 0) st_lv += walking ? 1u : 0u;
+                                if (STATS && c0 == 0) {
+                                    st_lv += walking ? 1u : 0u;
+                                    st_rec += lines_of(walking, (hn - first) * 64u);          // (node and leaf PDFs: one 64-byte record)
+                                    st_leaf += lines_of(ended, (h[k] & ~kDone) * 16u);
+                                    st_far += far_lines(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky, walking, img_boff);
+                                    st_far += far_lines(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky, walking, img_boff);
+                                }
                                 const int g = tprobe_value(qu) - tprobe_value(qv) - (int)n.lo16;
                                 const uint32_t next = walk_step(h[k], g, n.w2, n.flags);
                                 const bool right = walking && (next & 1u) != 0u;
@@ -1071,6 +1118,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             // 16-byte rows: (((tree << D) + node) * 2 + side) * (cpad / 4) + c0 / 4, node * 2 + side = h & ~kDone (add_leaf_pdf)
                             const size_t at = ((((size_t)tk << (a.D + 1)) + (h[k] & ~kDone)) * (size_t)(a.cpad >> 2)) + (size_t)(c0 >> 2);
                             row[k] = reinterpret_cast<const float4 *>(a.packed_pdf)[ended ? at : 0];
+                            if (STATS && c0 == 0) st_leaf += lines_of(ended, (uint32_t)at * 16u);
                         }
 #pragma unroll
                         for (int k = 0; k < GROUP; ++k) {
@@ -1154,15 +1202,12 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 
     if (STATS) {
         // wave reduction, one atomic per wave and counter
-        for (int o = 32; o > 0; o >>= 1) {
-            st_px += __shfl_down(st_px, o);
-            st_lv += __shfl_down(st_lv, o);
-            st_lf += __shfl_down(st_lf, o);
-        }
-        if (lane == 0) {
-            atomicAdd(a.stats + 0, st_px);
-            atomicAdd(a.stats + 1, st_lv);
-            atomicAdd(a.stats + 2, st_lf);
+        uint32_t c[8] = {st_px, st_lv, st_lf, st_lds, st_rec, st_leaf, st_far, st_blk};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned long long v = c[i];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0 && (i < 3 || a.stats_wide)) atomicAdd(a.stats + i, v);
         }
     }
 }
@@ -1857,7 +1902,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     const bool compaction = g_compaction != 0;
     const bool filtered_r1 = packed && filter_class != -1 && compaction && r == 1;
     if (block != 256 && block != 512) block = (big && !filtered_r1) ? 512 : 256;   // (other requests: the default)
-    if (stats) block = 256;
+    if (stats && !packed) block = 256;      // (the packed visit-counter kernels take the geometry of the launch they describe)
     const int rpw_knob = g_rows_per_wave;
     int rpw = rpw_knob > 0 ? rpw_knob : env_int("RDF_ROWS_PER_WAVE", 0);
     if (rpw < 1 || rpw > kMaxRowsPerWave) {
@@ -1966,7 +2011,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // deep blocks (k_eval_forest<..., DEEP>): from which root level on.  The knob or RDF_DEEP_FROM names a level (rounded up
     // to a block root, and never inside the levels LDS holds); the default is in deep_default().
     bool deep_launch = false;
-    if (packed && !tw && !stats && deep_bytes(n_trees, max_depth, n_classes) != 0) {
+    if (packed && !tw && deep_bytes(n_trees, max_depth, n_classes) != 0) {
         const int R0 = max_depth - deep_last_levels(a.cpad);
         const int knob = g_deep_from;
         int from = knob >= 0 ? knob : env_int("RDF_DEEP_FROM", -1);      // process-wide knob first,
@@ -2006,6 +2051,16 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         EvalArgsN<1> ka;
         ka.l[0] = a;
         rc = a.C <= 4 ? launch_multi<4, 1, true>(ka, lds_bytes, cus, st) : launch_multi<8, 1, true>(ka, lds_bytes, cus, st);
+    } else if (stats && packed) {
+        // the launch rdf_eval_forest_packed would make, with the visit and line counters on (four classes, no pixel list)
+        if (n_classes > 4 || compact_launch) return RDF_ERR_BAD_ARG;
+        a.stats_wide = 1;
+        if (deep_launch)
+            rc = block == 512 ? launch_one<512, true, 4, true, 4, false, true>(a, lds_bytes, cus, st)
+                              : launch_one<256, true, 4, true, 4, false, true>(a, lds_bytes, cus, st);
+        else
+            rc = block == 512 ? launch_one<512, true, 4, true, 4, false, false>(a, lds_bytes, cus, st)
+                              : launch_one<256, true, 4, true, 4, false, false>(a, lds_bytes, cus, st);
     } else if (stats) {   // (reference layout, 256 threads: eval_common chose both)
         rc = launch_one<256, false, 4, true, 4, false>(a, lds_bytes, cus, st);
     } else if (deep_launch) {
@@ -2180,6 +2235,16 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
     if (n_tried) *n_tried = n_cand;
     if (chosen_level) *chosen_level = best;
     return rdf_forest_set_deep_from(packed, best);
+}
+
+int rdf_eval_forest_packed_stats(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
+                                 const float *forest, int n_trees, int max_depth, int n_classes, uint16_t *labels_out,
+                                 int labels_reduce, unsigned long long *stats8, void *stream)
+{
+    if (!stats8 || !packed) return RDF_ERR_NULL_PTR;
+    if (max_depth > 27) return RDF_ERR_BAD_ARG;
+    return eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees, max_depth, n_classes, nullptr, -1, labels_out,
+                       labels_reduce, 1.0f, 0, stats8, stream);
 }
 
 int rdf_eval_forest_packed_filled(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,

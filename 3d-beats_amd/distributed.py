@@ -59,7 +59,10 @@ class ShardedForestEvaluator:
         self._step_no = 0
         self._inflight = {}
         self.gathered = None
-        if self.world > 1 and self.rank == dst:
+        # the gather runs whenever a process group exists -- with one rank too (bench.py --force-distributed puts the RCCL
+        # path on a one-GPU box that way); without torch.distributed there is nothing to gather
+        self.collective = dist.is_initialized()
+        if self.collective and self.rank == dst:
             self.gathered = DeviceArray((self.world, self.frames, self.lh, self.lw), np.uint16)
 
     def _torch_view(self, arr, first_frame, n_frames):
@@ -78,7 +81,7 @@ class ShardedForestEvaluator:
         for a, b in self.chunks:
             self.ev.get_labels_forest(self.forest, depth[a:b], labels[a:b], labels_reduce=self.r,
                                       scale_factor=self.s)
-            if self.world > 1:
+            if self.collective:
                 send = self._torch_view(labels, a, b - a)
                 if self.rank == self.dst:
                     recv = [self._torch_view(self.gathered[g], a, b - a) for g in range(self.world)]
@@ -108,7 +111,7 @@ class ShardedForestEvaluator:
         if prefill is not None:
             labels.fill(prefill)
         self.ev.get_labels_forest(self.forest, depth, labels, labels_reduce=self.r, scale_factor=self.s)
-        if self.world > 1:
+        if self.collective:
             send = self._torch_view(labels, 0, self.frames)
             recv = None
             if self.rank == self.dst:
@@ -124,7 +127,7 @@ class ShardedForestEvaluator:
                 self._inflight[slot] = None
 
     def result(self):
-        """Rank `dst`: DeviceArray [world*frames, lh, lw] of every rank's labels (world 1: None)."""
+        """Rank `dst`: DeviceArray [world*frames, lh, lw] of every rank's labels (no process group: None)."""
         if self.gathered is None:
             return None
         return self.gathered.reshape(self.world * self.frames, self.lh, self.lw)

@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline levels "
-                    "then come from the committed profiles/r03_roofline_counters.json and say so)")
+                    "then come from the committed profiles/r04_roofline_counters.json and say so)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the config-5 shard leg (2 GiB forest)")
     ap.add_argument("--cfg5-frames", type=int, default=32)
     ap.add_argument("--cfg5-trees", type=int, default=8, help="(tests shrink the config-5 forest)")
@@ -155,7 +155,7 @@ def cached(name, make):
 
 def committed_counters(key):
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03_roofline_counters.json"))).get(key)
+        return json.load(open(os.path.join(ROOT, "profiles", "r04_roofline_counters.json"))).get(key)
     except Exception:
         return None
 
@@ -180,7 +180,7 @@ def collect_counters(a, legs):
     return out
 
 
-def roofline_for(leg, key, live, kernel_ms, alg_bytes):
+def roofline_for(leg, key, live, kernel_ms, alg_bytes, useful=None):
     import roofline
     c = (live or {}).get(leg, {})
     vals, src, kern = c.get("counters"), c.get("source"), c.get("kernel")
@@ -188,8 +188,8 @@ def roofline_for(leg, key, live, kernel_ms, alg_bytes):
         com = committed_counters(key)
         if com:
             vals, kern = com.get("counters"), com.get("kernel")
-            src = "profiles/r03_roofline_counters.json (committed; this run collected none)"
-    r = roofline.model(vals, kernel_ms, alg_bytes)
+            src = "profiles/r04_roofline_counters.json (committed; this run collected none)"
+    r = roofline.model(vals, kernel_ms, alg_bytes, useful=useful)
     r["kernel"] = kern or "k_eval_forest"
     r["counters_source"] = src
     r["counters"] = {k: (int(v) if v == int(v) else round(v, 1)) for k, v in (vals or {}).items() if not k.startswith("_")}
@@ -256,6 +256,23 @@ def main():
             return None
         return forest_obj.tune(sample)
 
+    def useful_lines(forest_obj, depth_arr):
+        """The lines the timed launch needs from the L1 at the least (rdf_eval_forest_packed_stats: the same launch, same
+        geometry and table choice, with counters on) -- the useful-work numerator of the roofline's L1 level."""
+        if a.unpacked or int(forest_obj.num_classes) > 4:
+            return None, None
+        n_, h_, w_ = (int(v) for v in depth_arr.shape)
+        st8 = rdf.DeviceArray((8,), np.uint64).fill(0)
+        tmp = rdf.DeviceArray((n_, h_, w_), np.uint16).fill(65535)
+        rc_ = lib.rdf_eval_forest_packed_stats(depth_arr.ptr, n_, w_, h_, forest_obj.packed(1.0).ptr, forest_obj.forest_cu.ptr,
+                                               int(forest_obj.num_trees), int(forest_obj.max_depth), int(forest_obj.num_classes),
+                                               tmp.ptr, 1, st8.ptr, rt.stream())
+        if rc_ != 0:
+            return None, None
+        v = [int(x) for x in st8.get()]
+        del tmp
+        return {"records": v[4], "leaf_rows": v[5], "far_probes": v[6], "blocks": v[7]}, v
+
     def distinct_nodes(frames_sample, forest_arr, cores):
         """How much of every level the sample's walks really touch (oracle/rdf_oracle.c's visit map; summed over the trees)."""
         from oracle import rdf_oracle
@@ -290,8 +307,9 @@ def main():
         wall = (time.perf_counter() - t0) / steps
         kms = float(np.mean([e5.elapsed_ms(2 * i, 2 * i + 1) for i in range(steps)]))
         e5.destroy()
+        useful5, _ = useful_lines(forest5, depth5) if check else (None, None)
         res = {"value": round(F5 * H5 * W5 / wall / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(wall * 1e3, 4),
-               "kernel_ms": round(kms, 4), "steps": steps, "warmup": warmup,
+               "kernel_ms": round(kms, 4), "steps": steps, "warmup": warmup, "useful_lines": useful5,
                "workload": f"{F5} dense {W5}x{H5} frames, T{T5}/D{D5}/C{C5} {topology} forest (config 5's per-GPU shard), 1 GPU",
                "tune": tune5}
         if check:
@@ -765,7 +783,12 @@ def main():
             out["cfg5_all_ranks"] = c5n
 
     key = f"F{F}_T{T}_D{D}_C{C}_{a.topology}"
-    out["roofline"] = roofline_for("headline", key, live, kern_avg_ms, alg_bytes)
+    useful_h, st8_h = useful_lines(forest, depth) if full_run else (None, None)
+    if st8_h is not None:       # the packed launch's own counters agree with the reference-layout stats kernel's
+        assert st8_h[0:3] == [int(stats[0]), int(stats[1]), int(stats[2])], (st8_h, [int(v) for v in stats])
+    out["roofline"] = roofline_for("headline", key, live, kern_avg_ms, alg_bytes, useful_h)
+    if st8_h is not None:
+        out["roofline"]["node_records_from_lds"] = st8_h[3]
     out["roofline"]["algorithmic"].update({"bytes_per_pixel": round(alg_bytes / (F * H * W), 1),
                                            "visits": {"pixels": int(stats[0]), "node_records": int(stats[1]), "leaves": int(stats[2])}})
 
@@ -1047,7 +1070,10 @@ def main():
                                          "sample": f"one pass over the batch's first {ns} frames, {t_cpu:.2f} s"},
                         "distinct_nodes": distinct_nodes(frames_np[0:ns], fb_np, cores),
                         "distinct_nodes_full_topology": distinct_nodes(frames_np[0:ns], forest_np, cores) if a.topology == "full" else None})
-            res["batch"]["roofline"] = roofline_for("headline_balanced", f"F{F}_T{T}_D{D}_C{C}_balanced", live, ms_b, alg_b)
+            useful_b, st8_b = useful_lines(fb, depth)
+            if st8_b is not None:
+                assert st8_b[0:3] == [int(stats[0]), int(stats[0]) * T * D, int(stats[0]) * T], st8_b
+            res["batch"]["roofline"] = roofline_for("headline_balanced", f"F{F}_T{T}_D{D}_C{C}_balanced", live, ms_b, alg_b, useful_b)
             return res
 
         if not a.no_balanced and not a.unpacked:
@@ -1069,13 +1095,13 @@ def main():
             torch.cuda.empty_cache()
             c5 = leg_cfg5(5, 2, True)
             c5["roofline"] = roofline_for("cfg5", f"F{a.cfg5_frames}_T{a.cfg5_trees}_D{a.cfg5_depth}_C4_full_1280x720", live, c5["kernel_ms"],
-                                          c5.pop("algorithmic_bytes", None))
+                                          c5.pop("algorithmic_bytes", None), c5.pop("useful_lines", None))
             out["cfg5_shard"] = c5
             if not a.no_balanced and not a.unpacked:
                 try:
                     c5b = leg_cfg5(5, 2, True, "balanced")
                     c5b["roofline"] = roofline_for("cfg5_balanced", f"F{a.cfg5_frames}_T{a.cfg5_trees}_D{a.cfg5_depth}_C4_balanced_1280x720", live,
-                                                   c5b["kernel_ms"], c5b.pop("algorithmic_bytes", None))
+                                                   c5b["kernel_ms"], c5b.pop("algorithmic_bytes", None), c5b.pop("useful_lines", None))
                 except Exception as e:   # noqa: BLE001 -- the headline is measured; it must still be printed
                     c5b = {"error": f"{type(e).__name__}: {e}"[:400]}
                 out["cfg5_balanced"] = c5b

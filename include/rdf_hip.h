@@ -28,7 +28,7 @@ extern "C" {
 /* 2: rdf_forest_packed_bytes grew (last-level table behind the three per-slot tables: re-pack with this library's
  * rdf_forest_pack); new: rdf_set_last_level_table, rdf_eval_forest_packed_filled.  Nothing was removed or re-typed.
  * 3: rdf_forest_packed_bytes grew again (deep blocks behind the last-level table; `packed` must be 128-byte aligned);
- * new: rdf_set_deep_from, rdf_forest_set_deep_from, rdf_forest_tune.  Nothing was removed or re-typed. */
+ * new: rdf_set_deep_from, rdf_forest_set_deep_from, rdf_forest_tune, rdf_eval_forest_packed_stats.  Nothing was removed or re-typed. */
 #define RDF_ABI_VERSION 3
 
 #define RDF_OK 0
@@ -147,6 +147,21 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
                     float scale_factor, void *packed, void *stream);
+
+/*
+ * The launch rdf_eval_forest_packed would make for these arguments (same workgroup size, halo, LDS levels, table choice),
+ * with counters on; forests of up to four classes, no filter.  stats8 (8 x uint64, device memory, accumulated into):
+ *   [0] label pixels evaluated   [1] node records read   [2] leaves reached   (as rdf_eval_forest_stats)
+ *   [3] node records read from LDS
+ *   128-byte lines the loads that serve WALKING slots touch, per wave instruction, neighbouring lanes on one line merged
+ *   (what the L1 merges): [4] node records from global memory (last-level records included), [5] leaf rows of the PDF table,
+ *   [6] far probes that load (outside the staged tile, inside the image), [7] deep blocks.
+ * [4] + [5] + [6] + [7] is the least the launch needs from the L1 / texture-addresser pipeline with this geometry: the
+ * "useful" numerator of bench.py's roofline (tools/roofline.py), next to the issued accesses the hardware counts.
+ */
+int rdf_eval_forest_packed_stats(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
+                                 const float *forest, int n_trees, int max_depth, int n_classes, uint16_t *labels_out,
+                                 int labels_reduce, unsigned long long *stats8, void *stream);
 
 /*
  * Which table serves a packed forest's deep levels is a property of the forest AND of the frames: a forest whose deep levels

@@ -62,12 +62,12 @@ def test_code_object_targets_gfx950(rdf):
 
 def test_code_object_stays_small(rdf, tmp_path):
     """Every instantiation of the forest kernel costs compile time and code size; the dispatch in rdf_hip.hip lists the
-    ones launches really take.  Fewer than 70 of them (16 walk the deep blocks), and a library under 1.75 MB."""
+    ones launches really take.  Fewer than 75 of them (16 walk the deep blocks, 4 count visits and lines), and a library under 1.9 MB."""
     import shutil
     import subprocess
     from importlib import import_module
     so = import_module("3d-beats_amd._build").build()
-    assert os.path.getsize(so) < 1_750_000, os.path.getsize(so)
+    assert os.path.getsize(so) < 1_900_000, os.path.getsize(so)
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("no llvm-objdump")
@@ -80,7 +80,7 @@ def test_code_object_stays_small(rdf, tmp_path):
             out = subprocess.run([objdump, "-t", str(tmp_path / f)], capture_output=True, text=True).stdout
             kernels |= {l.split()[-1] for l in out.splitlines()
                         if "k_eval_forest" in l and " F " in l and not l.split()[-1].endswith(".kd")}
-    assert 0 < len(kernels) < 70, len(kernels)
+    assert 0 < len(kernels) < 75, len(kernels)
 
 
 def test_no_gpu_means_loud_failure_not_cpu_fallback(rdf):

@@ -1242,3 +1242,45 @@ def test_balanced_topology_config2_full_size(rdf, evs, oracle, gpu_runtime):
             assert np.array_equal(got, want), (level, int((got != want).sum()))
     finally:
         lib.rdf_set_deep_from(-1)
+
+
+def test_packed_stats_count_what_the_timed_launch_does(rdf, evs, oracle, gpu_runtime):
+    """rdf_eval_forest_packed_stats: the packed launch with counters on.  Pixels, node visits and leaves are the oracle's; the
+    line counters follow the table the launch walks (heap-order records / last-level records / deep blocks)."""
+    lib = gpu_runtime.lib
+    forest_np = _deep_forest(rdf, "balanced", 4, 14, 4, first_tree=77)
+    depth_np = rdf.synth.frames(["dense", "live", "dense"], 2100, 240, 424)
+    want = np.full(depth_np.shape, 65535, np.uint16)
+    st = np.zeros(3, np.uint64)
+    oracle.eval_forest(depth_np, forest_np, want, stats=st)
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    depth = rdf.to_device(depth_np)
+    packed = f.packed(1.0)
+    seen = {}
+    try:
+        for level in (0, 9, 12):
+            lib.rdf_set_deep_from(level)
+            out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+            st8 = rdf.DeviceArray((8,), np.uint64).fill(0)
+            rc = lib.rdf_eval_forest_packed_stats(depth.ptr, 3, 424, 240, packed.ptr, f.forest_cu.ptr, 4, 14, 4, out.ptr, 1, st8.ptr,
+                                                  gpu_runtime.stream())
+            assert rc == 0
+            v = [int(x) for x in st8.get()]
+            assert np.array_equal(out.get(), want)
+            assert v[0:3] == [int(st[0]), int(st[1]), int(st[2])], (level, v)
+            px, visits = v[0], v[1]
+            assert 0 < v[3] < visits and v[3] % 1 == 0                 # the top levels come from LDS
+            assert v[6] > 0                                           # some probes leave the staged tile
+            if level == 0:
+                assert v[7] == 0 and 0 < v[4] <= visits - v[3]        # one line or less per record read from global memory
+            else:
+                # blocks: one per walking (pixel, tree) and block level from `level` on; every walk reaches the last level
+                n_blocks = len(range(level, 12, 3)) + 1
+                assert v[7] == px * 4 * n_blocks, (level, v[7], px * 4 * n_blocks)
+                assert v[5] == 0                                      # the leaves come with the last block
+            seen[level] = v
+        assert seen[9][4] < seen[12][4] < seen[0][4]                  # fewer heap-order records the earlier the blocks take over
+        # refused: more than four classes, a NULL table
+        assert lib.rdf_eval_forest_packed_stats(depth.ptr, 3, 424, 240, None, f.forest_cu.ptr, 4, 14, 4, out.ptr, 1, st8.ptr, 0) != 0
+    finally:
+        lib.rdf_set_deep_from(-1)

@@ -56,3 +56,23 @@ def test_model_without_counters_says_so(roofline):
     m = roofline.model(None, 4.4, alg_bytes=1e9)
     assert m["bound"] is None and m["frac"] is None and m["levels"] == {}
     assert m["algorithmic"]["bytes_per_launch"] == 10 ** 9
+
+
+def test_useful_fraction_never_exceeds_the_utilisation(roofline):
+    """`useful_frac` prices the lines the walk needs (rdf_eval_forest_packed_stats), `frac` the accesses the kernel issued
+    (hardware counter): issued >= useful, so useful_frac <= frac, on the committed round-4 line and on a made-up launch."""
+    c = {"TCP_TCC_READ_REQ_sum": 0.76e9, "TCP_TOTAL_CACHE_ACCESSES_sum": 1.93e9, "SQ_INSTS_VALU": 1.8e9, "GRBM_GUI_ACTIVE": 8 * 8.8e6,
+         "_ns:GRBM_GUI_ACTIVE": 3.85e6}
+    useful = {"records": 1.0e9, "leaf_rows": 0.02e9, "far_probes": 0.45e9, "blocks": 0}
+    m = roofline.model(c, 3.85, useful=useful)
+    ta = m["levels"]["l1_ta"]
+    assert ta["useful_line_accesses_per_launch"] == int(1.47e9) and 0 < ta["useful_frac"] < ta["frac"] <= 1.0
+    assert ta["useful_share_of_issued"] == pytest.approx(1.47 / 1.93, abs=1e-3)
+    assert m["useful_frac"] == (ta["useful_frac"] if m["bound"] == "l1_ta" else m["frac"])
+    path = os.path.join(ROOT, "profiles", "r04_bench.json")
+    if os.path.exists(path):
+        line = json.load(open(path))
+        for r in (line["roofline"], line["cfg2_balanced"]["batch"]["roofline"], line["cfg5_balanced"]["roofline"]):
+            ta = r["levels"]["l1_ta"]
+            assert ta["useful_line_accesses_per_launch"] <= ta["l1_line_accesses_per_launch"]
+            assert ta["useful_frac"] <= ta["frac"] <= 1.0

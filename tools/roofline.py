@@ -131,8 +131,14 @@ def l1_cycles_per_access(share):
     return pts[-1][1]
 
 
-def model(counters, kernel_ms, alg_bytes=None, cus=CUS):
-    """The four levels for one launch; returns the `roofline` object of bench.py's JSON line."""
+def model(counters, kernel_ms, alg_bytes=None, cus=CUS, useful=None):
+    """The four levels for one launch; returns the `roofline` object of bench.py's JSON line.
+
+    `useful` (rdf_eval_forest_packed_stats, the same launch with counters on): {"records", "leaf_rows", "far_probes",
+    "blocks"} = 128-byte lines the loads that serve walking slots touch at the least.  With it the L1 level carries
+    `useful_frac`: those lines x the calibrated cycles per access against the kernel's cycles -- a useful-work fraction; the
+    level's own `frac` prices the accesses the hardware counted (TCP_TOTAL_CACHE_ACCESSES), i.e. it is a utilisation: a
+    kernel that issued twice the accesses it needs would show the same `frac` and half the `useful_frac`."""
     t = kernel_ms * 1e-3
     c = counters or {}
     levels = {}
@@ -181,6 +187,16 @@ def model(counters, kernel_ms, alg_bytes=None, cus=CUS):
                                                     if c.get("TA_TA_BUSY_sum") and c.get("_ns:TA_TA_BUSY_sum") else None),
                            "what": "L1 line accesses x the measured cycles per access at this launch's fill share "
                                    "(tools/ubench_l1_fill.hip) per CU against the kernel's cycles"}
+        if useful:
+            lines = float(sum(useful.get(k, 0) for k in ("records", "leaf_rows", "far_probes", "blocks")))
+            levels["l1_ta"].update({
+                "useful_line_accesses_per_launch": int(lines), "useful_by_kind": {k: int(v) for k, v in useful.items()},
+                "useful_share_of_issued": round(lines / acc, 4) if acc else None,
+                "useful_frac": round(lines * l1_cycles_per_access(share) / cus / cyc, 4),
+                "useful_what": "128-byte lines the loads serving walking slots must touch with this launch geometry (node records "
+                               "below the LDS levels, leaf rows, far probes that load, deep blocks; neighbouring lanes on one line "
+                               "merged) x the same cycles per access; the rest of the issued accesses is staging, finished slots' "
+                               "stand-in fetches and the second to seventh load of a line"})
     # ---- VALU issue ----
     valu = c.get("SQ_INSTS_VALU")
     if valu is not None:
@@ -198,6 +214,11 @@ def model(counters, kernel_ms, alg_bytes=None, cus=CUS):
         b = max(levels, key=lambda k: levels[k]["frac"])
         out.update({"bound": b, "achieved": levels[b]["achieved"], "peak": levels[b]["peak"], "unit": levels[b]["unit"],
                     "frac": levels[b]["frac"]})
+        if "useful_frac" in levels.get("l1_ta", {}):
+            out["useful_frac"] = levels["l1_ta"]["useful_frac"] if b == "l1_ta" else levels[b]["frac"]
+            out["useful_frac_what"] = ("the bounding level's fraction counted in useful work: for the L1 / texture-addresser level the "
+                                       "lines the walk needs instead of the accesses the kernel issued; the HBM, L2->L1 and VALU levels "
+                                       "count what the hardware moved or issued")
     else:
         out.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
     if alg_bytes is not None:
