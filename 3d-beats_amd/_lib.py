@@ -78,7 +78,7 @@ SIGNATURES = {
     "rdf_stream_capture_id": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
     "rdf_graph_slots_release": (_c_int, [ctypes.c_uint64]),
     "rdf_debug_sched_slots": (_c_int, [_c_void_p, _c_void_p]),
-    "rdf_debug_host_overhead": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int]),
+    "rdf_debug_host_overhead": (_c_int, [_c_void_p, _c_int]),
     "rdf_device_malloc": (_c_int, [_c_void_p, _c_size_t]),
     "rdf_device_free": (_c_int, [_c_void_p]),
     "rdf_ipc_export": (_c_int, [_c_void_p, _c_void_p]),

@@ -1451,7 +1451,7 @@ inline EnvVal read_env(const char *name)
 
 // C-side cost of a call (rdf_debug_host_overhead): nanoseconds eval_common spends before it hands the launch to the HIP
 // runtime, and inside the runtime's launch call
-std::atomic<unsigned long long> g_host_ns_plan{0}, g_host_ns_launch{0}, g_host_calls{0};
+std::atomic<unsigned long long> g_host_ns_plan{0}, g_host_ns_launch{0}, g_host_calls{0}, g_host_ns_layered{0}, g_host_layered_calls{0};
 inline unsigned long long now_ns()
 {
     struct timespec ts;
@@ -2395,9 +2395,13 @@ int rdf_layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers, c
                     uint16_t *composite_out, int32_t *bad_count, int labels_reduce, float scale_factor,
                     void *stream)
 {
-    return layered_run(depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes, filter_layer,
-                       filter_class, layer_labels, layer_labels_dev_table, cond, n_cond, composite_out, bad_count,
-                       labels_reduce, scale_factor, 0, nullptr, 0, nullptr, stream);
+    const unsigned long long t0 = now_ns();
+    const int rc = layered_run(depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes, filter_layer,
+                               filter_class, layer_labels, layer_labels_dev_table, cond, n_cond, composite_out, bad_count,
+                               labels_reduce, scale_factor, 0, nullptr, 0, nullptr, stream);
+    g_host_ns_layered.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+    g_host_layered_calls.fetch_add(1, std::memory_order_relaxed);
+    return rc;
 }
 
 int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_layers, const void *const *packed,
@@ -2408,9 +2412,13 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
                          int flip_x, const uint8_t *colors_rgba, int num_colors, uint8_t *image_rgba, void *stream)
 {
     if (num_colors < 0 || (image_rgba && num_colors > 0 && !colors_rgba)) return RDF_ERR_BAD_ARG;
-    return layered_run(depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes, filter_layer,
-                       filter_class, layer_labels, layer_labels_dev_table, cond, n_cond, composite_out, bad_count,
-                       labels_reduce, scale_factor, flip_x, colors_rgba, num_colors, image_rgba, stream);
+    const unsigned long long t0 = now_ns();
+    const int rc = layered_run(depth, dim_x, dim_y, n_layers, packed, forests, n_trees, max_depth, n_classes, filter_layer,
+                               filter_class, layer_labels, layer_labels_dev_table, cond, n_cond, composite_out, bad_count,
+                               labels_reduce, scale_factor, flip_x, colors_rgba, num_colors, image_rgba, stream);
+    g_host_ns_layered.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+    g_host_layered_calls.fetch_add(1, std::memory_order_relaxed);
+    return rc;
 }
 
 int rdf_fill_u16(uint16_t *dst, size_t n, uint16_t value, void *stream)
@@ -2527,15 +2535,17 @@ int rdf_graph_slots_release(unsigned long long capture_id)
     return n;
 }
 
-// measurement hook: what forest launches cost on the host since the last reset -- nanoseconds inside this library before the
-// launch is handed to the HIP runtime (argument checks, LDS plan, queue slot), nanoseconds inside the runtime's launch call,
-// number of launches (a layered run of n layers in one launch counts n plans and no launch: its launch is in rdf_layered_run)
-int rdf_debug_host_overhead(unsigned long long *ns_plan, unsigned long long *ns_launch, unsigned long long *calls, int reset)
+// measurement hook: what the calls cost on the host since the last reset.  out[0] nanoseconds inside this library before a
+// forest launch is handed to the HIP runtime (argument checks, LDS plan, queue slot), out[1] nanoseconds inside the runtime's
+// launch call, out[2] forest launches counted; out[3] nanoseconds inside rdf_layered_run[_hand] from entry to return (plans,
+// the forest launch(es) and the composite launch, runtime included), out[4] such calls
+int rdf_debug_host_overhead(unsigned long long out[5], int reset)
 {
-    if (ns_plan) *ns_plan = g_host_ns_plan.load();
-    if (ns_launch) *ns_launch = g_host_ns_launch.load();
-    if (calls) *calls = g_host_calls.load();
-    if (reset) { g_host_ns_plan = 0; g_host_ns_launch = 0; g_host_calls = 0; }
+    if (out) {
+        out[0] = g_host_ns_plan.load(); out[1] = g_host_ns_launch.load(); out[2] = g_host_calls.load();
+        out[3] = g_host_ns_layered.load(); out[4] = g_host_layered_calls.load();
+    }
+    if (reset) { g_host_ns_plan = 0; g_host_ns_launch = 0; g_host_calls = 0; g_host_ns_layered = 0; g_host_layered_calls = 0; }
     return RDF_OK;
 }
 

@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-balanced", action="store_true", help="skip the legs on forests whose deep levels are occupied "
                     "(cfg2_balanced, cfg5_balanced)")
     ap.add_argument("--no-tune", action="store_true", help="do not let DecisionForest.tune choose the deep-level table per forest")
+    ap.add_argument("--deep-from", type=int, default=None, help="the headline forest's deep-level table, fixed instead of tuned: 0 = heap-order "
+                    "records, N = deep blocks from level N (what tools/profile.sh passes, so that a kernel trace holds the timed launches only)")
     ap.add_argument("--leg", default=None, choices=["headline", "cfg2", "cfg5", "headline_balanced", "cfg5_balanced"],
                     help="internal: run ONE leg and print its kernel time (the program the --pmc passes profile)")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
@@ -254,6 +256,9 @@ def main():
         """Outside every timed region, like packing: which table serves the forest's deep levels (DecisionForest.tune)."""
         if a.unpacked or a.no_tune:
             return None
+        if a.deep_from is not None and a.headline_only:
+            assert lib.rdf_forest_set_deep_from(forest_obj.packed(1.0).ptr, int(a.deep_from)) == 0
+            return {"deep_from": int(a.deep_from), "tried": None}
         return forest_obj.tune(sample)
 
     def useful_lines(forest_obj, depth_arr):
@@ -838,7 +843,24 @@ def main():
             lf.run(dbuf, lbuf, 1.0)
         torch.cuda.synchronize()
         w3 = (time.perf_counter() - t3) / 100
-        out["cfg3_layered_run"] = {"ms_per_frame_wall": round(w3 * 1e3, 4), "value": round(H * W / w3 / 1e6, 2),
+        # what the calls cost on the HOST (rdf_debug_host_overhead): a sync-per-frame live loop pays this per frame
+        import ctypes
+        ho = (ctypes.c_ulonglong * 5)()
+        lib.rdf_debug_host_overhead(ho, 1)
+        for _ in range(200):
+            lf.run(dbuf, lbuf, 1.0)
+        lib.rdf_debug_host_overhead(ho, 1)
+        one_l3 = rdf.DeviceArray((1, H, W), np.uint16).fill(65535)
+        ho2 = (ctypes.c_ulonglong * 5)()
+        for _ in range(200):
+            ev.get_labels_forest(forest, depth[0:1], one_l3)
+        lib.rdf_debug_host_overhead(ho2, 1)
+        torch.cuda.synchronize()
+        host_overhead = {"rdf_layered_run_us_per_call_runtime_included": round(ho[3] / max(1, ho[4]) / 1e3, 2), "rdf_layered_run_calls": int(ho[4]),
+                         "rdf_eval_forest_packed_us_in_library_before_the_launch": round(ho2[0] / max(1, ho2[2]) / 1e3, 2),
+                         "rdf_eval_forest_packed_us_in_hip_launch": round(ho2[1] / max(1, ho2[2]) / 1e3, 2), "rdf_eval_forest_packed_calls": int(ho2[2]),
+                         "what": "CLOCK_MONOTONIC inside librdf_hip.so (rdf_debug_host_overhead), 200 calls each"}
+        out["cfg3_layered_run"] = {"ms_per_frame_wall": round(w3 * 1e3, 4), "value": round(H * W / w3 / 1e6, 2), "host_overhead": host_overhead,
                                    "unit": "Mpix/s", "what": "LayeredDecisionForest.run, 2 layers (second filtered on "
                                    "class 3 of the first), labels_reduce 2, one live-like 848x480 frame: ONE C-ABI call, both "
                                    "layers in one forest launch (unfiltered; the composite kernel applies the filter and "

@@ -379,9 +379,10 @@ int rdf_debug_floor_i32(const float *in, int32_t *out, size_t n, void *stream);
 /* Test hook: out[i] = num[i] / den[i] as the kernels compute it (IEEE fp32 divide). */
 int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, void *stream);
 
-/* Measurement hook: host-side cost of the forest launches since the last reset: nanoseconds spent inside this library before
- * a launch is handed to the HIP runtime, nanoseconds inside the runtime's launch call, launches counted (all nullable). */
-int rdf_debug_host_overhead(unsigned long long *ns_plan, unsigned long long *ns_launch, unsigned long long *calls, int reset);
+/* Measurement hook: host-side cost of the calls since the last reset.  out[0] nanoseconds spent inside this library before a
+ * forest launch is handed to the HIP runtime, out[1] nanoseconds inside the runtime's launch call, out[2] forest launches;
+ * out[3] nanoseconds inside rdf_layered_run[_hand] from entry to return (runtime included), out[4] such calls.  `out` nullable. */
+int rdf_debug_host_overhead(unsigned long long out[5], int reset);
 
 /* Tuning knobs (process-wide atomics, each read once per call; 0 restores the default).  Not part of the reference
  * surface.  The RDF_* environment variables that name the same choices are read once per process, at the first call that

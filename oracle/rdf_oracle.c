@@ -358,6 +358,45 @@ int rdf_oracle_visit_map(const uint16_t *depth, int n_img, int dim_x, int dim_y,
     return 0;
 }
 
+/*
+ * How many node records does every walk read?  levels_out (uint8 [n_img][dim_y/r][dim_x/r][n_trees]) gets the number of
+ * records the walk of that label pixel in that tree reads (0 for pixels the kernel returns early on).  Same walk as
+ * rdf_oracle_eval_forest without a filter; feeds tools/refill_bound.py (what refilling lanes could save at most).
+ */
+int rdf_oracle_walk_lengths(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                            const float *forest, int n_trees, int max_depth, int n_classes,
+                            int labels_reduce, float scale_factor, uint8_t *levels_out, int n_threads)
+{
+    if (n_img < 0 || dim_x < 0 || dim_y < 0 || n_trees < 0 || max_depth < 0 || max_depth > 30 ||
+        n_classes < 0 || labels_reduce < 1 || !levels_out)
+        return -1;
+    const int lw = dim_x / labels_reduce, lh = dim_y / labels_reduce;
+    const int64_t per_img = (int64_t)lw * lh;
+    const int64_t total = per_img * n_img;
+    const int64_t nodes = ((int64_t)1 << max_depth) - 1;
+    const int E = 7 + 2 * n_classes;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = omp_get_max_threads();
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(n_threads)
+    for (int64_t i = 0; i < total; i++) {
+        const int img = (int)(i / per_img);
+        const int64_t rem = i % per_img;
+        const int32_t y = (int32_t)(rem / lw) * labels_reduce, x = (int32_t)(rem % lw) * labels_reduce;
+        const uint16_t *frame = depth + (size_t)img * dim_x * dim_y;
+        const uint16_t d = depth_at(frame, dim_x, dim_y, y, x);
+        for (int k = 0; k < n_trees; k++) {
+            int lv = 0;
+            if (d != 0 && d != RDF_NO_PIXEL)
+                (void)walk(forest + (int64_t)k * nodes * E, max_depth, n_classes, frame, dim_x, dim_y, x, y, d, scale_factor, &lv);
+            levels_out[(size_t)i * n_trees + k] = (uint8_t)lv;
+        }
+    }
+    return 0;
+}
+
 int rdf_oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -41,6 +41,8 @@ def lib():
         L.rdf_oracle_max_threads.restype = i
         L.rdf_oracle_visit_map.argtypes = [p, i, i, i, p, i, i, i, i, f, p, i]
         L.rdf_oracle_visit_map.restype = i
+        L.rdf_oracle_walk_lengths.argtypes = [p, i, i, i, p, i, i, i, i, f, p, i]
+        L.rdf_oracle_walk_lengths.restype = i
         _lib = L
     return _lib
 
@@ -152,6 +154,20 @@ def distinct_nodes_per_level(depth, forest, labels_reduce=1, scale_factor=1.0, n
     out = np.zeros((T, D), np.int64)
     for j in range(D):
         out[:, j] = vis[:, (1 << j) - 1:(1 << (j + 1)) - 1].sum(axis=1, dtype=np.int64)
+    return out
+
+
+def walk_lengths(depth, forest, labels_reduce=1, scale_factor=1.0, n_threads=0):
+    """uint8 [N, H/r, W/r, T]: node records every walk reads (0: pixel not evaluated)."""
+    depth = _c(depth, np.uint16)
+    forest = _c(forest, np.float32)
+    n, h, w = depth.shape
+    T, D, C = _forest_dims(forest)
+    out = np.zeros((n, h // labels_reduce, w // labels_reduce, T), np.uint8)
+    rc = lib().rdf_oracle_walk_lengths(_ptr(depth), n, w, h, _ptr(forest), T, D, C, int(labels_reduce), float(scale_factor),
+                                       _ptr(out), int(n_threads))
+    if rc != 0:
+        raise ValueError("rdf_oracle_walk_lengths: bad arguments")
     return out
 
 

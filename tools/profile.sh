@@ -2,6 +2,8 @@
 # Kernel-trace stats of the headline workload (run through gpurun): rocprofv3's own average duration of the forest kernel
 # next to bench.py's hipEvent figure from the same traced run.  The counters (--pmc) are collected by bench.py itself.
 # usage: tools/profile.sh <tag> [bench args]    -> gpurun_out/<tag>/{kernel_stats.csv, bench_traced.json}
+# Pass the forest's deep-level table explicitly (--deep-from 0 for the headline's "full" topology, --deep-from 15 with
+# --topology balanced: what DecisionForest.tune picks) so that the trace holds no tuning launches of the same kernel.
 set -u
 TAG=${1:-prof}; shift || true
 cd /tmp && export TMPDIR=/tmp
