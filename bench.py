@@ -370,8 +370,10 @@ def main():
         forest5 = rdf.DecisionForest.from_numpy(np.asarray(f_np))
         depth5 = rdf.to_device(np.asarray(fr_np))
         lab5 = rdf.DeviceArray((F5, H5, W5), np.uint16).fill(65535)
+        tune5 = None
         if not a.unpacked:
             forest5.packed(1.0)
+            tune5 = tune_forest(forest5, depth5[0:min(8, F5)])      # (per rank, outside the timed regions; no collective inside)
         mine = lab5.torch_bytes()           # uint8: every backend gathers bytes
         slabs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
 
@@ -471,7 +473,7 @@ def main():
         res = {"value": round(pix * steps / t_gather / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(t_gather / steps * 1e3, 4),
                "value_kernel_only": round(pix * steps / t_kernel / 1e6, 2), "kernel_only_ms": round(t_kernel / steps * 1e3, 4),
                "n_gpus": world, "steps": steps, "warmup": warmup, "gather": "rccl gather to rank 0 inside the timed region",
-               "gather_check": check, "scaling": "weak", "p2p_direct_stores": direct,
+               "gather_check": check, "scaling": "weak", "p2p_direct_stores": direct, "deep_level_table_rank0": tune5,
                "workload": f"{world} x {F5} dense {W5}x{H5} frames, T{T5}/D{D5}/C{C5} full forest replicated "
                            f"(config 5{' itself' if world * F5 == 256 else ' shards'}), {world} GPUs"}
         del forest5, depth5, lab5, slabs
