@@ -179,6 +179,13 @@ struct EvalArgs {
     uint16_t *labels;
     unsigned long long *stats;
     int stats_wide;        // stats holds 8 counters (rdf_eval_forest_packed_stats), not 3
+#ifdef RDF_EXPERIMENT_REFILL_BOUND
+    // timing experiment (tools/refill_bound_gpu.py, not in the product build): what a wave's level loop would cost if lanes
+    // were refilled for free -- pass 1 records, per wave slot (image row x 64-column chunk), the sum and count of its lanes'
+    // longest walks; pass 2 runs every wave's level loop for the MEAN of them only (labels are then wrong)
+    unsigned int *x_sum, *x_cnt;
+    const unsigned char *x_limit;
+#endif
     unsigned int *sched;   // queue slot, or nullptr for static round-robin tiles
     uint32_t n_tiles;      // n_img * tiles_x * tiles_y
     uint32_t tiles_x;      // ceil(Wl / 64)
@@ -712,11 +719,21 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                     const bool fast_levels = PACKED || K > 0;
                     if (fast_levels) set_round_down(rcp_s);
 
-                    for (int j = 0; j < walk_levels; ++j) {
+#ifdef RDF_EXPERIMENT_REFILL_BOUND
+                    const uint32_t x_slot = (img * (uint32_t)a.Hl + (uint32_t)ly) * a.tiles_x + tx;
+                    const int x_levels = a.x_limit ? min(walk_levels, (int)a.x_limit[x_slot]) : walk_levels;
+                    int x_len = 0;
+#else
+                    const int x_levels = walk_levels;
+#endif
+                    for (int j = 0; j < x_levels; ++j) {
                         bool any = false;
 #pragma unroll
                         for (int k = 0; k < GROUP; ++k) any |= (int)h[k] > 0;
                         if (!__any(any)) break;
+#ifdef RDF_EXPERIMENT_REFILL_BOUND
+                        x_len = any ? j + 1 : x_len;
+#endif
 
                         const bool in_lds = j < K;
                         float df_e = df;     // (a copy the mode switches tie)
@@ -841,6 +858,12 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             h[k] = walking ? next : h[k];
                         }
                     }
+#ifdef RDF_EXPERIMENT_REFILL_BOUND
+                    if (a.x_sum) {
+                        atomicAdd(a.x_sum + x_slot, (unsigned)x_len);
+                        atomicAdd(a.x_cnt + x_slot, 1u);
+                    }
+#endif
                     // ---- deep blocks: the levels from a.deep_from on, one tree after the other.  A lane loads the seven records of
                     // its block -- one 128-byte line -- at once: one fill, and the L1 and L2 do not keep a line from one level
                     // to the next (a record fetched later from the same line was a second fetch from beyond L2 every time:
@@ -1826,6 +1849,10 @@ static size_t deep_bytes(int n_trees, int max_depth, int n_classes)
     return (deep_total_lines(n_trees, max_depth, classes_padded(n_classes)) + 2u) * 128u;
 }
 
+#ifdef RDF_EXPERIMENT_REFILL_BOUND
+unsigned int *g_x_sum = nullptr, *g_x_cnt = nullptr;
+const unsigned char *g_x_limit = nullptr;
+#endif
 Knob g_halo{-1};
 Knob g_lds_levels{-1};
 Knob g_tree_waves{-1};
@@ -2043,6 +2070,9 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     }
 
     a.sched = sched_slot(stream);
+#ifdef RDF_EXPERIMENT_REFILL_BOUND
+    a.x_sum = g_x_sum; a.x_cnt = g_x_cnt; a.x_limit = g_x_limit;
+#endif
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int cus = usable_cus(st, di.cus);   // a CU-masked stream holds fewer persistent workgroups
@@ -2624,6 +2654,13 @@ int rdf_event_elapsed_ms(void *start, void *stop, float *ms)
 }
 int rdf_event_destroy(void *event) { return (int)hipEventDestroy(reinterpret_cast<hipEvent_t>(event)); }
 int rdf_stream_synchronize(void *stream) { return (int)hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)); }
+
+#ifdef RDF_EXPERIMENT_REFILL_BOUND
+extern "C" void rdf_experiment_refill_bound(unsigned int *sum, unsigned int *cnt, const unsigned char *limit)
+{
+    g_x_sum = sum; g_x_cnt = cnt; g_x_limit = limit;
+}
+#endif
 
 int rdf_abi_version(void) { return RDF_ABI_VERSION; }
 
