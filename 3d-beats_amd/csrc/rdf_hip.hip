@@ -110,16 +110,22 @@ __device__ unsigned int g_sched[kSchedSlots + kGraphSlots][kSchedWords];
 // depth 1..65535 against integer floor division (logs under profiles/); tools/verify_intoffset.hip and
 // tools/verify_fastdiv.hip tie integer floor division to the reference's floor(IEEE (s*u)/d) for every fp32 numerator
 // that is +-0 or has a biased exponent in [40,147] (|a| < 2^21).  Any other numerator (huge, denormal, inf, NaN) flags
-// the node kFlagExact and the kernel takes the IEEE divide on the fp32 values of the exact record.
+// the node kFlagExact and the kernel takes the IEEE divide on the fp32 numerators s*u, s*v, which it recomputes -- the same
+// one multiply rdf_forest_pack did -- from the node's record in the caller's reference-layout forest (rounds 1-3 kept them in
+// a dense 32-byte table of their own, 128 MB for a T4/D20 forest that practically never has such a node).  rdf_forest_pack
+// counts the flagged nodes and notes the scale in the table's info block; a packed forest that has any needs the `forest`
+// argument at evaluation (RDF_ERR_NULL_PTR otherwise).
 struct alignas(16) NodeRec16 {
     uint32_t w[4];
 };
-// Exact record, 32 bytes: the fp32 numerators s*u, s*v (read only for kFlagExact nodes).
-struct alignas(16) NodeRec32 {
-    float sux, suy, svx, svy;
-    float thresh;
-    uint32_t flags, pad0, pad1;
+// What rdf_forest_pack leaves in the last 128 bytes of a packed table.
+struct PackInfo {
+    uint32_t exact_nodes;   // nodes flagged kFlagExact
+    float scale;            // the scale_factor the table was packed for
+    uint32_t magic;         // kPackMagic once k_pack has run
+    uint32_t pad[29];
 };
+constexpr uint32_t kPackMagic = 0x52444634u;   // "RDF4"
 // Last-level record, 64 bytes (forests of up to four classes): the hot record of a node of level D-1 and the PDFs of
 // its two leaves in ONE half cache line.  A walk that reaches level D-1 ends there (tree_eval.cu:95-128), so its last
 // node fetch and its leaf fetch are the same 128-byte line: fetched together they are one L1 fill instead of two
@@ -131,7 +137,7 @@ struct alignas(64) LastLevelRec {
     float pdf_left[4], pdf_right[4];
     uint32_t pad[4];
 };
-static_assert(sizeof(NodeRec16) == 16 && sizeof(NodeRec32) == 32 && sizeof(LastLevelRec) == 64, "record sizes");
+static_assert(sizeof(NodeRec16) == 16 && sizeof(PackInfo) == 128 && sizeof(LastLevelRec) == 64, "record sizes");
 
 // ---- deep blocks: the levels whose records no cache holds, three levels to a 128-byte line ---------------------------
 // A forest whose deep levels are OCCUPIED (a trained forest; synth's "balanced" topology) visits practically every node of
@@ -174,7 +180,6 @@ struct EvalArgs {
     const uint16_t *depth;
     const float *forest;
     const NodeRec16 *packed16;   // nullptr on the unpacked path
-    const NodeRec32 *packed32;
     const uint16_t *filter;
     uint16_t *labels;
     unsigned long long *stats;
@@ -790,11 +795,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                 for (int k = 0; k < GROUP; ++k) {
                                     if (n[k].flags & kFlagExact) {
                                         const int tk = min(kb + k, a.T - 1);
-                                        if (PACKED) {
-                                            const float4 e = *reinterpret_cast<const float4 *>(
-                                                a.packed32 + ((size_t)tk << a.D) + hn[k]);
-                                            n[k].ax = e.x; n[k].ay = e.y; n[k].bx = e.z; n[k].by = e.w;
-                                        } else {
+                                        {
+                                            // (packed tables too: the numerators are recomputed from the caller's forest with the
+                                            // scale the table was packed for, a.s -- one multiply, as rdf_forest_pack did)
                                             const float *p = a.forest +
                                                 ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
                                             n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1];
@@ -1235,8 +1238,8 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
     }
 }
 
-// ---- load-time repack: one thread per node; writes the 16-byte and the 32-byte table ----
-__global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, NodeRec32 *packed32,
+// ---- load-time repack: one thread per node; writes the hot records, the PDF rows, the last-level records, the deep blocks ----
+__global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, PackInfo *info,
                                               float *packed_pdf, LastLevelRec *last_level, unsigned int *last_level_unusable,
                                               uint4 *deep, int n_trees, int C, int cpad,
                                               size_t total_slots, int D, int E, float s, int force_exact)
@@ -1247,10 +1250,9 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     const size_t tree = slot >> D, h = slot & (((size_t)1 << D) - 1);
     if (h == 0) {
         NodeRec16 z16 = {{0u, 0u, 0u, 0u}};
-        NodeRec32 z32 = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
         packed16[slot] = z16;
-        packed32[slot] = z32;
         for (int c = 0; c < 2 * cpad; ++c) packed_pdf[slot * 2 * (size_t)cpad + c] = 0.f;
+        if (tree == 0) { info->scale = s; info->magic = kPackMagic; }
         if (deep && tree == 0) {     // the all-zero line behind the blocks
             uint4 *z = deep + (deep_total_lines(n_trees, D, cpad) << 3);
             for (int i = 0; i < 8; ++i) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1259,15 +1261,12 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
     }
     const size_t i = tree * ((((size_t)1) << D) - 1) + (h - 1);
     const float *p = forest + i * (size_t)E;
-    NodeRec32 n;
-    n.sux = s * p[0]; n.suy = s * p[1]; n.svx = s * p[2]; n.svy = s * p[3];
-    n.thresh = p[4];
-    NodeRec16 h16 = encode_node(n.sux, n.suy, n.svx, n.svy, p[4], p[5], p[6]);
+    struct { uint32_t flags; } n;
+    NodeRec16 h16 = encode_node(s * p[0], s * p[1], s * p[2], s * p[3], p[4], p[5], p[6]);
     if (force_exact) h16.w[3] |= kFlagExact;   // test knob: exercise the IEEE branch everywhere
     n.flags = h16.w[3] & 0xFFu;
-    n.pad0 = n.pad1 = 0;
     packed16[slot] = h16;
-    packed32[slot] = n;
+    if (n.flags & kFlagExact) atomicAdd(&info->exact_nodes, 1u);     // (practically never)
     float *q = packed_pdf + slot * 2 * (size_t)cpad;   // [left: cpad][right: cpad], the PDFs as stored (row N of SURVEY 8a)
     for (int c = 0; c < cpad; ++c) {
         q[c] = c < C ? p[7 + c] : 0.f;
@@ -1797,16 +1796,52 @@ int deep_default(int n_trees, int max_depth, int cpad, int K, bool big)
     return from;
 }
 
-// Per-forest choice (rdf_forest_set_deep_from / rdf_forest_tune): (device, packed table) -> level, 0 = never.
-std::map<std::pair<int, const void *>, int> g_forest_deep;
+// What the host knows about a packed table, per (device, table): the per-forest choice of the deep-level table
+// (rdf_forest_set_deep_from / rdf_forest_tune; level, 0 = never, -1 = none made) and what rdf_forest_pack found -- how many
+// nodes need the exact numerators (then evaluations need the caller's forest) and the scale the table was packed for.
+struct PackedState {
+    int deep_from = -1;
+    int exact_nodes = -1;      // -1: not read back yet
+    float scale = 1.0f;
+};
+std::map<std::pair<int, const void *>, PackedState> g_packed;
 
 int forest_deep_choice(const void *packed)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
     std::lock_guard<std::mutex> lock(g_sched_mu);
-    const auto it = g_forest_deep.find(std::make_pair(dev, packed));
-    return it == g_forest_deep.end() ? -1 : it->second;
+    const auto it = g_packed.find(std::make_pair(dev, packed));
+    return it == g_packed.end() ? -1 : it->second.deep_from;
+}
+
+// The table's info block as the host knows it; read back from the device once (a synchronous 128-byte copy behind whatever the
+// stream holds: rdf_forest_pack does it, and so does the first evaluation of a table this process did not pack at this
+// address).  Returns 0 and fills `out`, or an error code.
+int packed_info(const void *packed, const void *info_dev, void *stream, PackedState *out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    const auto key = std::make_pair(dev, packed);
+    {
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        const auto it = g_packed.find(key);
+        if (it != g_packed.end() && it->second.exact_nodes >= 0) { *out = it->second; return RDF_OK; }
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
+        return RDF_ERR_BAD_ARG;     // a table's first evaluation cannot be recorded into a graph: evaluate it once before capturing
+    PackInfo host;
+    hipError_t e = hipMemcpyAsync(&host, info_dev, sizeof(host), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return (int)e;
+    if (host.magic != kPackMagic) return RDF_ERR_BAD_ARG;       // not a table this library's rdf_forest_pack wrote (or another shape)
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    PackedState &st = g_packed[key];
+    st.exact_nodes = (int)(host.exact_nodes > 0x7FFFFFFFu ? 0x7FFFFFFFu : host.exact_nodes);
+    st.scale = host.scale;
+    *out = st;
+    return RDF_OK;
 }
 
 int check_common(const void *depth, int n_img, int dim_x, int dim_y, const void *forest, int n_trees,
@@ -1836,11 +1871,13 @@ static size_t last_level_bytes(int n_trees, int max_depth, int n_classes)
 }
 
 // the deep blocks behind the last-level table (128-byte aligned), one all-zero line and a 128-byte trailer
+static size_t slot_tables_bytes(int n_trees, int max_depth, int n_classes)      // hot records + PDF rows
+{
+    return ((size_t)n_trees << max_depth) * (sizeof(NodeRec16) + 2 * (size_t)classes_padded(n_classes) * sizeof(float));
+}
 static size_t deep_offset(int n_trees, int max_depth, int n_classes)
 {
-    const size_t before = ((size_t)n_trees << max_depth) *
-                              (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float)) +
-                          last_level_bytes(n_trees, max_depth, n_classes);
+    const size_t before = slot_tables_bytes(n_trees, max_depth, n_classes) + last_level_bytes(n_trees, max_depth, n_classes);
     return (before + 127u) & ~(size_t)127u;
 }
 static size_t deep_bytes(int n_trees, int max_depth, int n_classes)
@@ -1848,6 +1885,12 @@ static size_t deep_bytes(int n_trees, int max_depth, int n_classes)
     if (!deep_possible(n_trees, max_depth, classes_padded(n_classes))) return 0;
     return (deep_total_lines(n_trees, max_depth, classes_padded(n_classes)) + 2u) * 128u;
 }
+// the info block (PackInfo) is the table's last 128 bytes
+static size_t info_offset(int n_trees, int max_depth, int n_classes)
+{
+    return deep_offset(n_trees, max_depth, n_classes) + deep_bytes(n_trees, max_depth, n_classes);
+}
+
 
 #ifdef RDF_EXPERIMENT_REFILL_BOUND
 unsigned int *g_x_sum = nullptr, *g_x_cnt = nullptr;
@@ -1876,7 +1919,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
                 unsigned long long *stats, void *stream, int fill_untouched = 0, Plan *plan_only = nullptr, bool allow_tw = true)
 {
     const unsigned long long t_entry = now_ns();
-    int rc = check_common(depth, n_img, dim_x, dim_y, forest, n_trees, max_depth, n_classes, labels_out, r);
+    // (a packed table stands in for the forest: the forest itself is only needed for nodes that take the exact numerators, below)
+    int rc = check_common(depth, n_img, dim_x, dim_y, forest ? (const void *)forest : packed, n_trees, max_depth, n_classes, labels_out, r);
     if (rc == 1) {
         if (plan_only) plan_only->empty = true;
         return RDF_OK;
@@ -1904,9 +1948,14 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (packed) {
         const size_t slots = (size_t)n_trees << max_depth;   // 1-based heap slots, 2^D per tree
         a.packed16 = reinterpret_cast<const NodeRec16 *>(packed);
-        a.packed32 = reinterpret_cast<const NodeRec32 *>(a.packed16 + slots);
-        a.packed_pdf = reinterpret_cast<const float *>(a.packed32 + slots);
+        a.packed_pdf = reinterpret_cast<const float *>(a.packed16 + slots);
         a.cpad = (n_classes + 3) & ~3;
+        // nodes that need the exact numerators read them from the caller's forest, with the scale the table was packed for
+        PackedState ps;
+        rc = packed_info(packed, reinterpret_cast<const char *>(packed) + info_offset(n_trees, max_depth, n_classes), stream, &ps);
+        if (rc != RDF_OK) return rc;
+        if (ps.exact_nodes > 0 && !forest) return RDF_ERR_NULL_PTR;
+        a.s = ps.scale;
     }
 
     a.tiles_x = ((uint32_t)a.Wl + 63u) / 64u;
@@ -2138,11 +2187,8 @@ int rdf_eval_tree(const uint16_t *depth, int n_img, int dim_x, int dim_y, const 
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes)
 {
     if (n_trees < 0 || max_depth < 0 || max_depth > 30 || n_classes < 0) return 0;
-    const size_t deep = deep_bytes(n_trees, max_depth, n_classes);
-    if (deep != 0) return deep_offset(n_trees, max_depth, n_classes) + deep;
-    return ((size_t)n_trees << max_depth) *
-           (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float)) +
-           last_level_bytes(n_trees, max_depth, n_classes);
+    if (((size_t)n_trees << max_depth) == 0 || max_depth == 0) return 0;
+    return info_offset(n_trees, max_depth, n_classes) + sizeof(PackInfo);
 }
 
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes, float scale_factor,
@@ -2155,8 +2201,13 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
     if (!forest || !packed) return RDF_ERR_NULL_PTR;
     const size_t blocks = (total + 255) / 256;
     if (blocks >= (1ull << 31)) return RDF_ERR_TOO_LARGE;
-    char *tail = reinterpret_cast<char *>(packed) +
-                 total * (sizeof(NodeRec16) + sizeof(NodeRec32) + 2 * (size_t)classes_padded(n_classes) * sizeof(float));
+    if ((reinterpret_cast<uintptr_t>(packed) & 127u) != 0) return RDF_ERR_BAD_ARG;     // `packed` must be 128-byte aligned
+    char *tail = reinterpret_cast<char *>(packed) + slot_tables_bytes(n_trees, max_depth, n_classes);
+    PackInfo *info = reinterpret_cast<PackInfo *>(reinterpret_cast<char *>(packed) + info_offset(n_trees, max_depth, n_classes));
+    {
+        const hipError_t e = hipMemsetAsync(info, 0, sizeof(PackInfo), reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
     LastLevelRec *last_level = nullptr;
     unsigned int *unusable = nullptr;
     if (last_level_bytes(n_trees, max_depth, n_classes) != 0) {
@@ -2165,11 +2216,11 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
         const hipError_t e = hipMemsetAsync(unusable, 0, 64, reinterpret_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
     }
-    {   // a re-packed table is another forest: its per-forest choice goes
+    {   // a re-packed table is another forest: what the host knew of the old one goes
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) {
             std::lock_guard<std::mutex> lock(g_sched_mu);
-            g_forest_deep.erase(std::make_pair(dev, (const void *)packed));
+            g_packed.erase(std::make_pair(dev, (const void *)packed));
         }
     }
     uint4 *deep = nullptr;
@@ -2181,12 +2232,16 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       forest, reinterpret_cast<NodeRec16 *>(packed),
-                       reinterpret_cast<NodeRec32 *>(reinterpret_cast<NodeRec16 *>(packed) + total),
-                       reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * (sizeof(NodeRec16) + sizeof(NodeRec32))),
+                       forest, reinterpret_cast<NodeRec16 *>(packed), info,
+                       reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * sizeof(NodeRec16)),
                        last_level, unusable, deep, n_trees, n_classes, classes_padded(n_classes), total,
                        max_depth, 7 + 2 * n_classes, scale_factor, (int)g_force_exact);
-    return (int)hipGetLastError();
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return (int)le;
+    // what the kernel found (nodes that need the exact numerators) comes back now: packing is load time, and evaluations -- also
+    // those recorded into a hipGraph -- then never have to ask the device
+    PackedState ps;
+    return packed_info(packed, info, stream, &ps);
 }
 
 int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
@@ -2210,8 +2265,7 @@ int rdf_forest_set_deep_from(const void *packed, int level)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_sched_mu);
-    if (level < 0) g_forest_deep.erase(std::make_pair(dev, packed));
-    else g_forest_deep[std::make_pair(dev, packed)] = level;
+    g_packed[std::make_pair(dev, packed)].deep_from = level < 0 ? -1 : level;
     return RDF_OK;
 }
 

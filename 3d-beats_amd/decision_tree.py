@@ -78,7 +78,7 @@ class DecisionForest:
         self._packed = {}  # scale_factor -> (forest_cu identity, version, DeviceArray)
 
     def packed(self, scale_factor=1.):
-        """Packed tables (16-byte hot records + 32-byte exact records) for `scale_factor`, rebuilt when forest_cu
+        """Packed tables (16-byte hot records, PDF rows, last-level records, deep blocks) for `scale_factor`, rebuilt when forest_cu
         has been written since.
 
         The reference has no such step (its load is the upload at decision_tree.py:148-158); this is

@@ -752,7 +752,7 @@ def main():
                                f"half dense, half live-like), T{T}/D{D}/C{C} {a.topology} forest, "
                                + (f"labels gathered to rank 0 ({gather_mode}; control plane {a.backend}) inside the timed region" if multi else "1 GPU"),
                    "frames_per_gpu": F, "frame": [H, W], "trees": T, "tree_depth": D, "classes": C,
-                   "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16+exact32",
+                   "topology": a.topology, "forest_layout": "reference" if a.unpacked else "packed16",
                    "pipeline_chunks": chunks, "tile_schedule": a.scheduler, "cus_left_to_rccl": results[primary]["reserve"],
                    "gather": gather_mode,
                    "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if multi else None)),

@@ -117,32 +117,30 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
                          int num_colors, uint8_t *image_rgba, void *stream);
 
 /*
- * Load-time repack of a forest into a table of 16-byte hot records {23-bit floor(s*u), 23-bit
- * floor(s*v), integer threshold, leaf flags} followed by a table of 32-byte exact records
- * (fp32 s*u, s*v) that is read only for nodes whose numerators the integer form cannot
- * represent, followed by the leaf PDFs as 16-byte aligned rows [left: C padded to a multiple of 4]
- * [right: ...] per node.  The reference has no counterpart: its "load" is the plain upload at
- * src/decision_tree.py:148-158.  The packed tables depend on scale_factor and must be rebuilt
- * when the forest changes.  `packed` is caller-owned, rdf_forest_packed_bytes() bytes
- * (48 + 8 * (n_classes rounded up to 4) per heap slot, 2^max_depth slots per tree).  Packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
- * Forests of up to four classes and two or more levels carry a fourth table behind those three: one 64-byte record per
- * node of the deepest level, {hot record, left PDF, right PDF}, and a 64-byte trailer: word 0 counts the records that
- * are not ordinary nodes with two leaves, word 1 the records whose parent continues to them.  When word 0 is zero and
- * word 1 is at least half the level, a walk takes its last node and its leaf PDF from one cache line
- * (rdf_set_last_level_table); otherwise the table is ignored.
- * Forests of up to eight classes and five or more levels carry a fifth table, 128-byte aligned: the hot records once more,
+ * Load-time repack of a forest into a table of 16-byte hot records {23-bit floor(s*u), 23-bit floor(s*v), integer threshold,
+ * leaf flags} followed by the leaf PDFs as 16-byte aligned rows [left: C padded to a multiple of 4][right: ...] per node.
+ * The reference has no counterpart: its "load" is the plain upload at src/decision_tree.py:148-158.  The packed tables depend
+ * on scale_factor and must be rebuilt when the forest changes.  `packed` is caller-owned, 128-byte aligned,
+ * rdf_forest_packed_bytes() bytes; packed tables support max_depth <= 27 (32-bit byte offsets inside one tree).
+ * A node whose numerators s*u, s*v the integer record cannot hold (|a| >= 2^21, denormal, inf, NaN) is flagged and takes the
+ * IEEE divide on the fp32 numerators, which the kernel recomputes from the node's record in the caller's reference-layout
+ * forest: rdf_forest_pack counts such nodes, and a packed table that has any needs the `forest` argument at evaluation
+ * (RDF_ERR_NULL_PTR otherwise); the count, the scale and a mark sit in the table's last 128 bytes, and rdf_forest_pack waits
+ * for them (it is load-time work), so that evaluations -- also those recorded into a hipGraph -- never ask the device.
+ * Forests of up to four classes and two or more levels carry a table of one 64-byte record per node of the deepest level,
+ * {hot record, left PDF, right PDF}, and a 64-byte trailer: word 0 counts the records that are not ordinary nodes with two
+ * leaves, word 1 the records whose parent continues to them.  When word 0 is zero and word 1 is at least half the level, a walk
+ * takes its last node and its leaf PDF from one cache line (rdf_set_last_level_table); otherwise the table is ignored.
+ * Forests of up to eight classes and five or more levels carry the deep blocks, 128-byte aligned: the hot records once more,
  * grouped into three-level subtrees of seven records per 128-byte line, the last two levels together with their four leaf
  * PDFs in one line (five to eight classes: the last level's node with its two PDFs), one all-zero line and a 128-byte
- * trailer {1 + deepest level holding a node that needs the exact record, nodes of the last level that are not plain
- * two-leaf nodes}.  Launches walk the levels no cache holds from it, a third of the line fetches per walk
- * (rdf_set_deep_from).  `packed` must be 128-byte aligned.
- * Footprint, per heap slot (2^max_depth slots per tree): 16 B hot + 32 B exact + 8 B x classes (padded to 4) of leaf PDFs,
- * + 32 B (half a 64-byte record per slot of the deepest level; up to four classes) + ~37 B of deep blocks (128 B per
- * seven nodes plus 128 B per node of level D - 2): a T4/D20/C4 forest (240 MiB as .npy) packs into 64 + 128 + 128 + 128 +
- * 146 MiB = 594 MiB, T8/D22/C4 (1.9 GiB) into 4.6 GiB -- 2.5 x the model, 1.6 % of one MI355X's HBM; every table exists so
- * that a walk touches ONE cache line where the .npy layout touches two or three.  The exact table stays dense although
- * almost no forest has a node that needs it: the size must follow from (trees, depth, classes) alone, before the forest
- * is seen.
+ * trailer {1 + deepest level holding a flagged node, nodes of the last level that are not plain two-leaf nodes}.  Launches
+ * walk the levels no cache holds from it, a third of the line fetches per walk (rdf_set_deep_from).
+ * Footprint, per heap slot (2^max_depth slots per tree): 16 B hot + 8 B x classes (padded to 4) of leaf PDFs, + 32 B (half a
+ * 64-byte record per slot of the deepest level; up to four classes) + ~37 B of deep blocks (128 B per seven nodes plus 128 B
+ * per node of level D - 2): a T4/D20/C4 forest (240 MiB as .npy) packs into 64 + 128 + 128 + 146 MiB = 466 MiB, T8/D22/C4
+ * (1.9 GiB) into 3.6 GiB -- 1.9 x the model, 1.3 % of one MI355X's HBM; every table exists so that a walk touches ONE cache
+ * line where the .npy layout touches two or three.
  */
 size_t rdf_forest_packed_bytes(int n_trees, int max_depth, int n_classes);
 int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_classes,
@@ -179,8 +177,10 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
                     int n_trees, int max_depth, int n_classes, uint16_t *labels_scratch, int labels_reduce, void *stream,
                     int *chosen_level, int *n_tried, int *levels_tried, float *ms_tried);
 
-/* rdf_eval_forest on a packed table (hot records, exact records and leaf PDFs are all read from `packed`); `forest`
- * (original layout) is only used when `packed` is NULL for a degenerate forest (no tree or depth 0). */
+/* rdf_eval_forest on a packed table (hot records and leaf PDFs are read from `packed`); `forest` (original layout, the
+ * array the table was packed from) is read for the nodes that need the exact numerators -- it may be NULL for a table that
+ * has none (RDF_ERR_NULL_PTR otherwise) -- and stands in when `packed` is NULL for a degenerate forest (no tree or depth 0).
+ * A buffer that rdf_forest_pack did not write (for these trees / depth / classes) is refused with RDF_ERR_BAD_ARG. */
 int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_y,
                            const void *packed, const float *forest,
                            int n_trees, int max_depth, int n_classes,

@@ -37,19 +37,21 @@ def test_binding_table_matches_header(rdf):
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
     assert lib.rdf_abi_version() == _lib.ABI_VERSION
-    # three tables per heap slot; up to four classes: the 64-byte records of the deepest level and a 64-byte trailer; up to
-    # eight classes and five levels or more: the deep blocks (128-byte aligned), a zero line and a 128-byte trailer
+    # two tables per heap slot (16-byte hot record, PDF rows); up to four classes: the 64-byte records of the deepest level and a
+    # 64-byte trailer; up to eight classes and five levels or more: the deep blocks (128-byte aligned), a zero line and a
+    # 128-byte trailer; last: the 128-byte info block
     def deep(T, D, last):       # lines: three-level blocks rooted on levels R0 - 3, R0 - 6, ... >= 0, then the last blocks
         r0 = D - last
         return T * (((1 << r0) - (1 << (r0 % 3))) // 7) + (T << r0) + 2
 
     def up128(n):
         return (n + 127) & ~127
-    assert lib.rdf_forest_packed_bytes(4, 20, 4) == up128((4 << 20) * (48 + 32) + (4 << 19) * 64 + 64) + deep(4, 20, 2) * 128
-    assert lib.rdf_forest_packed_bytes(2, 1, 3) == (2 << 1) * (48 + 32)
-    assert lib.rdf_forest_packed_bytes(2, 4, 3) == (2 << 4) * (48 + 32) + (2 << 3) * 64 + 64
-    assert lib.rdf_forest_packed_bytes(3, 10, 5) == up128((3 << 10) * (48 + 64)) + deep(3, 10, 1) * 128
-    assert lib.rdf_forest_packed_bytes(3, 10, 9) == (3 << 10) * (48 + 96)
+    assert lib.rdf_forest_packed_bytes(4, 20, 4) == up128((4 << 20) * (16 + 32) + (4 << 19) * 64 + 64) + deep(4, 20, 2) * 128 + 128
+    assert lib.rdf_forest_packed_bytes(2, 1, 3) == up128((2 << 1) * (16 + 32)) + 128
+    assert lib.rdf_forest_packed_bytes(2, 4, 3) == up128((2 << 4) * (16 + 32) + (2 << 3) * 64 + 64) + 128
+    assert lib.rdf_forest_packed_bytes(3, 10, 5) == up128((3 << 10) * (16 + 64)) + deep(3, 10, 1) * 128 + 128
+    assert lib.rdf_forest_packed_bytes(3, 10, 9) == up128((3 << 10) * (16 + 96)) + 128
+    assert lib.rdf_forest_packed_bytes(0, 10, 4) == 0 and lib.rdf_forest_packed_bytes(4, 0, 4) == 0
     assert b"2^31" in lib.rdf_error_string(-3)
 
 

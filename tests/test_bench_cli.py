@@ -44,6 +44,20 @@ def test_single_gpu_line_has_roofline_and_legs(tmp_path):
     assert d["roofline"]["algorithmic"]["bytes_per_launch"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and "differ in 0 pixels" in d["cpu_baseline"]["sample"]
     assert d["cfg2_single_frame"]["kernel_ms"] > 0 and d["cfg3_layered_run"]["ms_per_frame_wall"] > 0
+    # round 4: the top level names the bound, the rate per evaluated pixel and the balanced forest's rate; the forest's deep-level
+    # table was chosen by DecisionForest.tune; the L1 level carries a useful-work fraction next to its utilisation
+    assert "bound" in d and "hbm_frac" in d and 0 < d["value_valid_pixels"] < d["value"] and 0 < d["valid_pixel_share"] < 1
+    assert "roofline.bound" in d["metric"] and d["metric"].startswith("classified Mpix/s on 848x480 depth frames (4 trees, depth 20)")
+    assert d["config"]["deep_level_table"]["deep_from"] in [int(k) for k in d["config"]["deep_level_table"]["tried"]]
+    ta = d["roofline"]["levels"].get("l1_ta")
+    if ta:      # (levels come from the committed counters here: --no-counters)
+        assert ta["useful_line_accesses_per_launch"] > 0 and ta["useful_frac"] > 0
+    b = d["cfg2_balanced"]
+    assert "error" not in b, b
+    assert b["topology"] == "balanced" and b["parity"]["differing_pixels"] == 0 and b["batch"]["value"] > 0 and d["value_balanced"] == b["batch"]["value"]
+    assert len(b["distinct_nodes"]["per_level"]) == 12 and b["distinct_nodes"]["share_of_level"][11] > 2 * b["distinct_nodes_full_topology"]["share_of_level"][11]
+    ho = d["cfg3_layered_run"]["host_overhead"]
+    assert ho["rdf_layered_run_calls"] == 200 and ho["rdf_eval_forest_packed_calls"] == 200 and ho["rdf_eval_forest_packed_us_in_library_before_the_launch"] < 20
 
 
 @pytest.mark.gpu

@@ -993,8 +993,8 @@ def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_o
     packed = forest.packed(1.0)
     gpu_runtime.synchronize()
     slots = trees << levels
-    trailer = slots * (48 + 32) + (trees << (levels - 1)) * 64
-    assert packed.nbytes >= trailer + 64           # (the deep blocks follow, 128-byte aligned)
+    trailer = slots * (16 + 32) + (trees << (levels - 1)) * 64
+    assert packed.nbytes >= trailer + 64           # (the deep blocks follow, 128-byte aligned; the info block is last)
     unusable, in_use = (int(x) for x in packed.get()[trailer:trailer + 8].view(np.uint32))
     # the deep blocks' trailer says the same in its own words: 1 + the deepest level with a node that needs the exact record,
     # and the nodes of the last level that are not plain two-leaf nodes
@@ -1002,11 +1002,15 @@ def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_o
         deep_at = (trailer + 64 + 127) & ~127
         r0 = levels - 2
         deep_lines = trees * (((1 << r0) - (1 << (r0 % 3))) // 7) + (trees << r0)
-        assert packed.nbytes == deep_at + (deep_lines + 2) * 128
+        assert packed.nbytes == deep_at + (deep_lines + 2) * 128 + 128
         exact_below, last_bad = (int(x) for x in packed.get()[deep_at + (deep_lines + 1) * 128:][:8].view(np.uint32))
         assert exact_below == (levels if spoil == "huge_numerator" else 0) and last_bad == unusable
     else:
-        assert packed.nbytes == trailer + 64
+        assert packed.nbytes == ((trailer + 64 + 127) & ~127) + 128
+    # the info block: nodes that need the exact numerators (they are read from the caller's forest), the scale, the mark
+    info = packed.get()[packed.nbytes - 128:][:12]
+    assert int(info[0:4].view(np.uint32)[0]) == (1 if spoil == "huge_numerator" else 0)
+    assert float(info[4:8].view(np.float32)[0]) == 1.0 and int(info[8:12].view(np.uint32)[0]) == 0x52444634
     assert unusable == (1 if spoil in ("continue_flag", "huge_numerator") else 0)
     # word 1: the deepest nodes some parent continues to (the default takes the table from half of the level on)
     to_child = f_np[:, first // 2:first, 5:7].reshape(trees, -1)
@@ -1284,3 +1288,32 @@ def test_packed_stats_count_what_the_timed_launch_does(rdf, evs, oracle, gpu_run
         assert lib.rdf_eval_forest_packed_stats(depth.ptr, 3, 424, 240, None, f.forest_cu.ptr, 4, 14, 4, out.ptr, 1, st8.ptr, 0) != 0
     finally:
         lib.rdf_set_deep_from(-1)
+
+
+def test_exact_numerators_come_from_the_callers_forest(rdf, evs, oracle, gpu_runtime):
+    """A packed table keeps no copy of the fp32 numerators: a node whose numerators the integer record cannot hold (huge,
+    denormal, non-finite) reads them from the reference-layout forest the caller passes along, scaled as rdf_forest_pack
+    scaled them.  Such a table refuses an evaluation without the forest; a table without such nodes does not need it."""
+    lib = gpu_runtime.lib
+    depth_np = rdf.synth.frames(["dense", "live"], 3100, 96, 160)
+    depth = rdf.to_device(depth_np)
+    plain = rdf.synth.forest(3, 9, 4, "full", 5)
+    wild = plain.copy()
+    wild[1, 7, 0] = 3.0e7
+    wild[2, 100, 3] = 1e-41
+    wild[0, 300, 2] = np.inf
+    for forest_np, needs in ((plain, False), (wild, True)):
+        for s_ in (1.0, 0.37):
+            f = rdf.DecisionForest.from_numpy(forest_np)
+            packed = f.packed(s_)
+            want = np.full(depth_np.shape, 65535, np.uint16)
+            oracle.eval_forest(depth_np, forest_np, want, 1, None, None, s_)
+            out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+            rc = lib.rdf_eval_forest_packed(depth.ptr, 2, 160, 96, packed.ptr, f.forest_cu.ptr, 3, 9, 4, None, -1, out.ptr, 1, gpu_runtime.stream())
+            assert rc == 0 and np.array_equal(out.get(), want), (needs, s_)
+            out.fill(65535)
+            rc = lib.rdf_eval_forest_packed(depth.ptr, 2, 160, 96, packed.ptr, None, 3, 9, 4, None, -1, out.ptr, 1, gpu_runtime.stream())
+            if needs:
+                assert rc == -2                          # RDF_ERR_NULL_PTR
+            else:
+                assert rc == 0 and np.array_equal(out.get(), want)

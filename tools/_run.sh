@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r04p
-O=gpurun_out/r04p
-timeout -k 10 300 python3 tools/refill_bound_gpu.py > $O/refill_gpu.txt 2>&1; echo "rc=$?"; grep -v amdgpu.ids $O/refill_gpu.txt
-timeout -k 10 300 python3 tools/refill_bound_gpu.py --topology full --frames 32 >> $O/refill_gpu.txt 2>&1; echo "rc=$?"; grep -v amdgpu.ids $O/refill_gpu.txt | tail -5
+mkdir -p gpurun_out/r04r
+O=gpurun_out/r04r
+python3 -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "rc=$?" >> $O/pytest_gpu.txt; tail -n 6 $O/pytest_gpu.txt
+python3 __graft_entry__.py smoke 2>&1 | tail -n 2
