@@ -924,8 +924,15 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                     const size_t base_at = (deep_lines_before(a.T, R, Lmin) + ((size_t)tk << R) - ((size_t)1 << R)) << 7;
                                     const uint32_t off = (int)hk[w] > 0 ? hk[w] << 7 : (uint32_t)(zero_at - base_at);
                                     const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.deep) + base_at + off);
+#ifdef RDF_EXPERIMENT_ONE_LOAD_PER_BLOCK
+                                    // timing experiment (labels wrong): what a block would cost if ONE access per lane brought it --
+                                    // the floor under any scheme that loads a line cooperatively (profiles/r04_deep_variants.txt)
+#pragma unroll
+                                    for (int i = 0; i < 7; ++i) q[i][w] = bp[0];
+#else
 #pragma unroll
                                     for (int i = 0; i < 7; ++i) q[i][w] = bp[i];
+#endif
                                     if (STATS && c0 == 0) st_blk += (int)hk[w] > 0 ? 1u : 0u;     // (a block is a line of its own)
                                 }
                                 // (issued together -- the line is filled once -- before anything is decoded)
