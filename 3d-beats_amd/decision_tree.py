@@ -97,6 +97,7 @@ class DecisionForest:
         _lib.check(lib, lib.rdf_forest_pack(device_ptr(self.forest_cu), int(self.num_trees), int(self.max_depth),
                                             int(self.num_classes), s, buf.ptr, rt.stream()), "rdf_forest_pack")
         self._packed[s] = (key, buf)
+        self.__dict__.setdefault("_tuned", {}).pop(s, None)      # a new table: its deep-level choice is made again
         return buf
 
     def tune(self, depth_images_in, labels_reduce=1, scale_factor=1.):
@@ -118,7 +119,9 @@ class DecisionForest:
                                             int(self.num_trees), int(self.max_depth), int(self.num_classes), scratch.ptr,
                                             int(labels_reduce), rt.stream(), ctypes.byref(chosen), ctypes.byref(tried),
                                             levels, ms), "rdf_forest_tune")
-        return {"deep_from": int(chosen.value), "tried": {int(levels[i]): round(float(ms[i]), 4) for i in range(tried.value)}}
+        res = {"deep_from": int(chosen.value), "tried": {int(levels[i]): round(float(ms[i]), 4) for i in range(tried.value)}}
+        self.__dict__.setdefault("_tuned", {})[float(np.float32(scale_factor))] = res      # (an evaluator's auto-tune then leaves it alone)
+        return res
 
 
 class LayeredDecisionForest:
@@ -339,6 +342,7 @@ class DecisionTreeEvaluator:
         packed = None
         if self.use_packed and hasattr(forest, "packed") and forest.max_depth <= 27:
             packed = forest.packed(scale_factor)
+            self._maybe_tune(forest, depth_images_in, labels_reduce, scale_factor)
         for i0, n in _image_chunks(num_images, dim_y * dim_x):
             d = _at(depth_images_in, i0, dim_y * dim_x * 2)
             o = _at(labels_out, i0, lpix * 2)
@@ -359,6 +363,33 @@ class DecisionTreeEvaluator:
         _touch(labels_out)
 
     evaluate = get_labels_forest  # the name BASELINE.json's north_star uses; not in the reference
+
+    # forests from this size on (hot records) may or may not be served better by the deep blocks: see DecisionForest.tune
+    AUTO_TUNE_HOT_BYTES = 32 << 20
+    AUTO_TUNE_PIXELS = 8 * 480 * 848
+
+    def _maybe_tune(self, forest, depth_images_in, labels_reduce, scale_factor):
+        """The first batch-sized evaluation of a big packed forest chooses its deep-level table by measurement
+        (DecisionForest.tune on up to 16 of the batch's own frames, about two dozen extra launches, once per packed table):
+        which table is faster depends on where the frames send the walks, which nothing in the forest's records tells.
+        `auto_tune = False` on the evaluator, or a DecisionForest.tune() of one's own before, turns it off; a
+        stream that is being captured into a hipGraph is never tuned on."""
+        if not getattr(self, "auto_tune", True) or not hasattr(forest, "tune") or not hasattr(self._lib, "rdf_forest_tune"):
+            return
+        s = float(np.float32(scale_factor))
+        done = forest.__dict__.setdefault("_tuned", {})
+        if s in done:
+            return
+        n, h, w = (int(v) for v in depth_images_in.shape)
+        if (int(forest.num_trees) << int(forest.max_depth)) * 16 < self.AUTO_TUNE_HOT_BYTES or n * h * w < self.AUTO_TUNE_PIXELS:
+            return
+        try:
+            import torch
+            if torch.cuda.is_current_stream_capturing():
+                return
+        except Exception:       # noqa: BLE001 -- (no torch runtime behind this evaluator: the host test double)
+            return
+        done[s] = forest.tune(depth_images_in[0:min(16, n)], labels_reduce, scale_factor)
 
     # -- composite: make_composite_labels_image ------------------------------------------------
     def make_composite_labels_image(self, images, dim_x, dim_y, labels_decision_tree, composite_image):

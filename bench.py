@@ -241,6 +241,7 @@ def main():
     lib = rt.lib
     lib.rdf_set_scheduler({"dynamic": 1, "static": 0, "tile": 2}[a.scheduler])
     ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
+    ev.auto_tune = not a.no_tune       # (every forest of this run is tuned explicitly, outside the timed regions: tune_forest)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -258,6 +259,7 @@ def main():
             return None
         if a.deep_from is not None and a.headline_only:
             assert lib.rdf_forest_set_deep_from(forest_obj.packed(1.0).ptr, int(a.deep_from)) == 0
+            forest_obj.__dict__.setdefault("_tuned", {})[1.0] = {"deep_from": int(a.deep_from), "tried": None}   # (no auto-tune on top)
             return {"deep_from": int(a.deep_from), "tried": None}
         return forest_obj.tune(sample)
 

@@ -1317,3 +1317,33 @@ def test_exact_numerators_come_from_the_callers_forest(rdf, evs, oracle, gpu_run
                 assert rc == -2                          # RDF_ERR_NULL_PTR
             else:
                 assert rc == 0 and np.array_equal(out.get(), want)
+
+
+def test_first_big_evaluation_tunes_a_big_forest_once(rdf, oracle, gpu_runtime):
+    """DecisionTreeEvaluator picks a big packed forest's deep-level table by measurement at its first batch-sized evaluation
+    (and only then); small forests, small launches and evaluators with auto_tune off are left alone."""
+    forest_np = rdf.synth.forest(4, 19, 4, "full", 31)              # 32 MB of hot records: the size from which the choice is open
+    depth_np = rdf.synth.mixed_batch(10, 5200, 480, 848)
+    depth = rdf.to_device(depth_np)
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    ev = rdf.DecisionTreeEvaluator()
+    out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+    ev.get_labels_forest(f, depth[0:2], out[0:2])                   # two frames: not a batch
+    assert not f.__dict__.get("_tuned")
+    ev.get_labels_forest(f, depth, out)
+    tuned = f.__dict__["_tuned"][1.0]
+    assert tuned["deep_from"] in tuned["tried"] and 0 in tuned["tried"] and len(tuned["tried"]) >= 4
+    want = np.full((3,) + depth_np.shape[1:], 65535, np.uint16)
+    oracle.eval_forest(depth_np[0:3], forest_np, want)
+    assert np.array_equal(out[0:3].get(), want)
+    before = dict(f.__dict__["_tuned"])
+    ev.get_labels_forest(f, depth, out)
+    assert f.__dict__["_tuned"] == before                           # once
+    small = rdf.DecisionForest.from_numpy(rdf.synth.forest(4, 12, 4, "full", 32))
+    ev.get_labels_forest(small, depth, out)
+    assert not small.__dict__.get("_tuned")
+    f2 = rdf.DecisionForest.from_numpy(forest_np)
+    ev_off = rdf.DecisionTreeEvaluator()
+    ev_off.auto_tune = False
+    ev_off.get_labels_forest(f2, depth, out)
+    assert not f2.__dict__.get("_tuned")
