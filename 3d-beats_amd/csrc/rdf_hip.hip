@@ -163,7 +163,8 @@ static_assert(sizeof(NodeRec16) == 16 && sizeof(PackInfo) == 128 && sizeof(LastL
 __host__ __device__ inline int deep_last_levels(int cpad) { return cpad == 4 ? 2 : 1; }
 __host__ __device__ inline bool deep_possible(int n_trees, int max_depth, int cpad)
 {
-    return n_trees >= 1 && (cpad == 4 || cpad == 8) && max_depth >= 5 && max_depth <= 27;
+    // (a lane's byte offset inside the blocks of one root level is heap index x 128 in 32 bits: root levels up to 22)
+    return n_trees >= 1 && (cpad == 4 || cpad == 8) && max_depth >= 5 && max_depth <= 24;
 }
 // lines of every block level whose root level is below R (R, Lmin members of the series R0 - 3 i)
 __host__ __device__ inline size_t deep_lines_before(int n_trees, int R, int Lmin)
@@ -343,6 +344,27 @@ struct EvalArgsN {
     EvalArgs l[NL];
 };
 
+// ---- a reader's map of k_eval_forest (one kernel, ~900 lines; the template parameters select code, never semantics) ----
+//   template parameters   BLOCK threads per workgroup | PACKED tables or the reference's records | CMAX classes summed in
+//                         registers at a time | STATS visit / line counters | GROUP trees a lane walks interleaved | COMPACT
+//                         pixel list (filtered launches) | NL layers of a stack in one launch | TW one wave per tree (small
+//                         launches) | DEEP walk the deep levels from the deep blocks
+//   per workgroup, once   "stage the top K levels": the node table's top levels into LDS; which tables serve the forest
+//                         (last-level table, deep blocks: their trailers)
+//   per tile              "take the next tile" (static first tile, then the per-XCD queues) -> "empty tile?" -> "stage depth" into
+//                         LDS at address 0 -> "compact" (COMPACT only)
+//   per pixel group       early-outs (tree_eval.cu:81-89), the pixel's reciprocal, then per CMAX classes and per GROUP trees:
+//       the level loop    round-down mode; node fetch (LDS / packed table / reference records) -> probe coordinates (one fma per
+//                         coordinate, or the IEEE divide for flagged nodes) -> probes issued -> decisions (walk_step)
+//       then ONE of       "deep blocks" (DEEP: whole 128-byte blocks, tree after tree, leaf PDFs with the last block)
+//                         "level D-1 from the last-level table" (node and both PDFs in one 64-byte record, tree after tree)
+//                         the general leaf fetch (PDF rows, in tree order)
+//       argmax (tree_eval.cu:7-21) and the label store
+//   TW only               "the T waves of a pixel row hand their trees' results to the row's first wave"
+//   epilogue              queue slot back to zero; STATS reduction
+// Bit-exactness rests on three things the sections keep apart: the order of the PDF adds (tree order, round-to-nearest), the
+// mode the fmas run in (round-down, between set_round_down / set_round_nearest: tools/check_rounding_isa.py), and the per-axis
+// bounds of the probes (TileCtx).
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT, int NL = 1, bool TW = false, bool DEEP = false>
 // second launch bound = waves per SIMD the register allocation must allow: three 512-thread workgroups per CU are six
 // waves per SIMD (80 VGPRs; the 4-wide walk needs 86 without the bound and spills two dwords with it)

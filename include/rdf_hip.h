@@ -131,7 +131,7 @@ int rdf_layered_run_hand(const uint16_t *depth, int dim_x, int dim_y, int n_laye
  * {hot record, left PDF, right PDF}, and a 64-byte trailer: word 0 counts the records that are not ordinary nodes with two
  * leaves, word 1 the records whose parent continues to them.  When word 0 is zero and word 1 is at least half the level, a walk
  * takes its last node and its leaf PDF from one cache line (rdf_set_last_level_table); otherwise the table is ignored.
- * Forests of up to eight classes and five or more levels carry the deep blocks, 128-byte aligned: the hot records once more,
+ * Forests of up to eight classes and five to twenty-four levels carry the deep blocks, 128-byte aligned: the hot records once more,
  * grouped into three-level subtrees of seven records per 128-byte line, the last two levels together with their four leaf
  * PDFs in one line (five to eight classes: the last level's node with its two PDFs), one all-zero line and a 128-byte
  * trailer {1 + deepest level holding a flagged node, nodes of the last level that are not plain two-leaf nodes}.  Launches
