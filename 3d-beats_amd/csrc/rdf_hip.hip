@@ -1738,13 +1738,15 @@ int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st
     return (int)hipGetLastError();
 }
 
-// Which instantiations exist (49 kernels; every one costs a second of compile time and ~20 KB of code object, so the list is
+// Which instantiations exist (69 kernels; every one costs half a second of compile time and ~20 KB of code object, so the list is
 // what launches really take -- rows per wave, halo, LDS levels, scheduler are run-time arguments):
 //   packed table, no pixel list:         256 / 512 threads x 4 / 8 / 16 classes in registers x 1 / 2 / 3 / 4 trees in a lane
 //   packed table, filtered (pixel list): 256 / 512 threads x 4 / 8 / 16 classes x 4 trees in a lane
 //   reference-layout forest:             256 / 512 threads x 4 / 16 classes x 1 or 4 trees in a lane (a filtered launch
 //                                        takes the early-outs per lane instead of listing pixels)
 //   visit counters (rdf_eval_forest_stats): reference layout, 256 threads, classes four at a time
+//   visit and line counters of a packed launch (rdf_eval_forest_packed_stats): 256 / 512 threads, four classes, heap-order / deep
+//   deep blocks (launch_deep):           256 / 512 threads x 4 / 8 classes x 2 / 3 / 4 trees in a lane + the pixel-list variant
 //   layers of a stack / tree waves in one launch: launch_multi, 4 / 8 classes
 // A lane walks GROUP trees interleaved: forests of one, two, three or six trees (and `rdf_eval_tree`) get kernels without the
 // idle slots of the 4-wide one (measured: T = 1 costs 54 % of T = 4 with idle slots).  rdf_set_group overrides the choice by
