@@ -1110,6 +1110,10 @@ def main():
             import bench_legs
             leg("unpacked", leg_unpacked)
             leg("cfg2_trained", leg_trained)
+            if not a.no_balanced and not a.unpacked:
+                leg("cfg2_trainer_forest", lambda: bench_legs.trainer_forest(
+                    rdf, frames_np, T, D, train_frames=np.asarray(cached(f"frames_mixed_64_{H}x{W}_at20000",
+                                                                        lambda: synth.mixed_batch(64, first_idx=20000, h=H, w=W)))))
             leg("hand_pipeline", lambda: bench_legs.hand_pipeline(rdf))
             leg("mean_shift", lambda: bench_legs.mean_shift(rdf))
             leg("train", lambda: bench_legs.train(rdf))

@@ -1347,3 +1347,50 @@ def test_first_big_evaluation_tunes_a_big_forest_once(rdf, oracle, gpu_runtime):
     ev_off.auto_tune = False
     ev_off.get_labels_forest(f2, depth, out)
     assert not f2.__dict__.get("_tuned")
+
+
+def test_deep_blocks_fuzz(rdf, evs, oracle, gpu_runtime):
+    """Seeded fuzz of the deep-block walk: random trees (1-9), depths (5-15), classes (1-8), topologies (balanced, trained-like,
+    full; a few wild nodes), frames, labels_reduce, scale, filter, pre-fill, take-over level and launch geometry -- every
+    combination bit-exact against the C oracle.  RDF_DEEP_FUZZ_ROUNDS / RDF_FUZZ_SEED for soaks (profiles/r04_fuzz_soak.log)."""
+    rounds = int(os.environ.get("RDF_DEEP_FUZZ_ROUNDS", "40"))
+    rng = np.random.default_rng(int(os.environ.get("RDF_FUZZ_SEED", "20261004")) + 17)
+    lib = gpu_runtime.lib
+    calib = rdf.synth.calibration_frames(3, 96, 160)
+    try:
+        for it in range(rounds):
+            T, D, C = int(rng.integers(1, 10)), int(rng.integers(5, 16)), int(rng.integers(1, 9))
+            topology = str(rng.choice(["balanced", "balanced", "trained", "full"]))
+            forest = (rdf.synth.forest(T, D, C, "balanced", first_tree=it, calib=calib) if topology == "balanced"
+                      else rdf.synth.forest(T, D, C, topology, first_tree=it))
+            if rng.random() < 0.25:     # wild nodes somewhere in the upper half of the levels: blocks below them stay usable
+                lvl = int(rng.integers(0, max(1, D // 2)))
+                node = (1 << lvl) - 1 + int(rng.integers(0, 1 << lvl))
+                forest[int(rng.integers(0, T)), node, int(rng.integers(0, 4))] = rng.choice([3e7, np.inf, np.nan, 1e-41])
+            n, h, w = int(rng.integers(1, 4)), int(rng.integers(8, 120)), int(rng.integers(8, 260))
+            if rng.random() < 0.5:
+                w = max(8, w & ~7)
+            r = int(rng.choice([1, 1, 2, 3]))
+            s = float(rng.choice([1.0, 0.5, 1.5]))
+            depth = rdf.synth.frames([str(k) for k in rng.choice(["dense", "live"], size=n)], 8000 + it, h, w)
+            use_filter = rng.random() < 0.3
+            filt = rng.integers(0, 3, size=(n, h // r, w // r)).astype(np.uint16) if use_filter else None
+            prefill = int(rng.choice([65535, 0]))
+            last = 2 if C <= 4 else 1
+            roots = list(range((D - last) % 3, D - last + 1, 3))
+            lib.rdf_set_deep_from(int(rng.choice(roots + [1, D])))
+            lib.rdf_set_block_threads(int(rng.choice([0, 256, 512])))
+            lib.rdf_set_halo(int(rng.choice([-1, -1, 8, 40])))
+            lib.rdf_set_lds_levels(int(rng.choice([-1, -1, 0, 3])))
+            lib.rdf_set_rows_per_wave(int(rng.choice([0, 1, 2, 4])))
+            lib.rdf_set_group(int(rng.choice([0, 0, 2, 3, 4])))
+            lib.rdf_set_scheduler(int(rng.choice([-1, 0, 1, 2])))
+            lib.rdf_set_tree_waves(0)
+            want = np.full((n, h // r, w // r), prefill, np.uint16)
+            oracle.eval_forest(depth, forest, want, r, filt, 2 if use_filter else None, s)
+            got = _gpu_forest(rdf, evs["packed"], depth, forest, prefill, r, filt, 2 if use_filter else None, s)
+            assert np.array_equal(got, want), f"iteration {it}: {topology} T{T} D{D} C{C} {n}x{h}x{w} r{r} s{s} filter {use_filter}"
+    finally:
+        for knob, v in (("deep_from", -1), ("block_threads", 0), ("halo", -1), ("lds_levels", -1), ("rows_per_wave", 0), ("group", 0),
+                        ("scheduler", -1), ("tree_waves", -1)):
+            getattr(lib, "rdf_set_" + knob)(v)

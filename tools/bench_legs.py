@@ -223,3 +223,73 @@ def train(rdf, images=64, depth=12, proposals=256, blocks=1, noisy_labels=False,
                          "numpy_restatement_s": round(cpu, 2)}
         assert differing == 0, out["parity"]
     return out
+
+
+def trainer_forest(rdf, frames_np, trees=4, depth=20, images=64, proposals=512, train_frames=None):
+    """A forest produced by THIS repo's trainer (DecisionTreeTrainer) instead of a synthetic topology: `trees` trees of depth
+    `depth` trained on `images` frames of the bench's mix labelled by a teacher (a balanced tree's labels: something a deep
+    tree can fit), evaluated on the headline's batch `frames_np`: nodes the trainer wrote and the batch visits per level, the
+    table DecisionForest.tune picks, the batch rate, four frames against the oracle.  (tools/trained_forest_probe.py is the
+    stand-alone version.)"""
+    import torch
+    from oracle import rdf_oracle
+    from test_training import _ArrayDataset
+    synth = rdf.synth
+    n, h, w = frames_np.shape
+    C = 4
+    t0 = time.perf_counter()
+    if train_frames is None:
+        train_frames = synth.mixed_batch(images, 20000, h, w)
+    images = int(train_frames.shape[0])
+    teacher = synth.forest(1, min(16, depth), C, "balanced")
+    lab = np.full(train_frames.shape, 65535, np.uint16)
+    rdf_oracle.eval_forest(train_frames, teacher, lab)
+    labels = np.where(lab == 65535, 0, 1 + lab % (C - 1)).astype(np.uint16)          # 0 = unlabelled, classes 1 .. C-1
+    ds = _ArrayDataset(train_frames, labels, C, per_block=images)
+    trainer = rdf.DecisionTreeTrainer(images, proposals)
+    trainer.allocate(ds, proposals, depth)
+    tree = rdf.DecisionTree(depth, C)
+    forest_np = np.zeros((trees, (1 << depth) - 1, 7 + 2 * C), np.float32)
+    train_s = []
+    for k in range(trees):
+        np.random.seed(1000 + k)
+        tt = time.perf_counter()
+        trainer.train(ds, tree)
+        torch.cuda.synchronize()
+        train_s.append(round(time.perf_counter() - tt, 2))
+        forest_np[k] = tree.tree_out_cu.get()
+    used = np.abs(forest_np).sum(axis=2) > 0
+    written = [int(used[:, (1 << j) - 1:(1 << (j + 1)) - 1].sum()) for j in range(depth)]
+    del trainer, ds
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    depth_dev = rdf.to_device(frames_np)
+    tune = f.tune(depth_dev[0:min(16, n)])
+    ev = rdf.DecisionTreeEvaluator()
+    out = rdf.DeviceArray(frames_np.shape, np.uint16).fill(65535)
+    rt = rdf.get_runtime()
+    for _ in range(2):
+        ev.get_labels_forest(f, depth_dev, out)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(7):
+        tt = time.perf_counter()
+        ev.get_labels_forest(f, depth_dev, out)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - tt)
+    ms = float(np.median(ts)) * 1e3
+    ns = min(4, n)
+    want = np.full((ns, h, w), 65535, np.uint16)
+    rdf_oracle.eval_forest(frames_np[0:ns], forest_np, want)
+    mism = int((want != out[0:ns].get()).sum())
+    assert mism == 0, f"trainer-produced forest: GPU labels differ from the oracle in {mism} pixels"
+    visited = rdf_oracle.distinct_nodes_per_level(frames_np[0:min(8, n)], forest_np).sum(axis=0)
+    lv = rdf_oracle.walk_lengths(frames_np[0:min(8, n)], forest_np)
+    valid = lv.max(axis=3) > 0
+    return {"value": round(n * h * w / ms / 1e3, 2), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "frames": n,
+            "forest": f"T{trees}/D{depth}/C{C} trained by DecisionTreeTrainer on {images} teacher-labelled frames, {proposals} proposals per level",
+            "train_seconds_per_tree": train_s, "nodes_written_per_level": written,
+            "nodes_visited_per_level_by_8_frames": [int(v) for v in visited],
+            "share_of_level_visited": [round(float(v) / (trees << j), 4) for j, v in enumerate(visited)],
+            "levels_per_pixel_and_tree": round(float(lv[valid].mean()), 2), "tune": tune,
+            "parity": {"frames_checked": ns, "differing_pixels": mism, "checker": "oracle/rdf_oracle.c on the host"},
+            "setup_seconds": round(time.perf_counter() - t0, 1)}
