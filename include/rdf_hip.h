@@ -169,7 +169,8 @@ int rdf_eval_forest_packed_stats(const uint16_t *depth, int n_img, int dim_x, in
  * default by forest size); rdf_forest_pack into the same memory forgets it.  rdf_forest_tune makes the choice by
  * measurement: it evaluates the caller's sample frames (device memory; results go to `labels_scratch`, uint16
  * [n_img][dim_y/r][dim_x/r]) with every candidate -- never, and each block root level -- four launches each, keeps the
- * fastest and reports what it tried (up to 12 entries in levels_tried / ms_tried, all three outputs nullable).  Synchronous.
+ * fastest (the deep blocks must beat the heap-order records by 2 %: a tie goes to the default) and reports what it tried
+ * (up to 12 entries in levels_tried / ms_tried, all three outputs nullable).  Synchronous.
  * Labels do not depend on the choice.  The process-wide knob rdf_set_deep_from (>= 0) overrides both.
  */
 int rdf_forest_set_deep_from(const void *packed, int level);
