@@ -952,8 +952,13 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
 #pragma unroll
                                     for (int i = 0; i < 7; ++i) q[i][w] = bp[0];
 #else
+                                    // (five to eight classes, last block {node, pad, left PDF, right PDF}: records 1 and 6 hold nothing)
+                                    const bool short_block = CMAX == 8 && R == R0;
 #pragma unroll
-                                    for (int i = 0; i < 7; ++i) q[i][w] = bp[i];
+                                    for (int i = 0; i < 7; ++i) {
+                                        if (CMAX == 8 && (i == 1 || i == 6) && short_block) q[i][w] = make_uint4(0u, 0u, 0u, 0u);
+                                        else q[i][w] = bp[i];
+                                    }
 #endif
                                     if (STATS && c0 == 0) st_blk += (int)hk[w] > 0 ? 1u : 0u;     // (a block is a line of its own)
                                 }
@@ -2325,7 +2330,8 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
     for (int c = 0; c < n_cand && rc == RDF_OK; ++c) {
         rc = rdf_forest_set_deep_from(packed, cand[c]);
         float ms_min = 0.f;
-        for (int rep = 0; rep < 4 && rc == RDF_OK; ++rep) {      // one warm-up, the fastest of three
+        int reps = 4;                                            // one warm-up, then the fastest of three ... twelve launches:
+        for (int rep = 0; rep < reps && rc == RDF_OK; ++rep) {   // short launches are repeated until ~10 ms have been timed
             (void)hipEventRecord(e0, st);
             rc = eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees, max_depth, n_classes, nullptr, -1,
                              labels_scratch, labels_reduce, 1.0f, 0, nullptr, stream);
@@ -2336,6 +2342,10 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
             if (e != hipSuccess) { rc = (int)e; break; }
             if (rep >= 1 && (rep == 1 || ms < ms_min)) ms_min = ms;
+            if (rep == 1 && ms > 0.f) {
+                const int want = 1 + (int)(10.0f / ms + 0.999f);
+                reps = want < 4 ? 4 : want > 13 ? 13 : want;
+            }
         }
         if (levels_tried) levels_tried[c] = cand[c];
         if (ms_tried) ms_tried[c] = ms_min;

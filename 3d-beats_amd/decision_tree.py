@@ -370,7 +370,7 @@ class DecisionTreeEvaluator:
 
     def _maybe_tune(self, forest, depth_images_in, labels_reduce, scale_factor):
         """The first batch-sized evaluation of a big packed forest chooses its deep-level table by measurement
-        (DecisionForest.tune on up to 16 of the batch's own frames, about two dozen extra launches, once per packed table):
+        (DecisionForest.tune on up to 32 of the batch's own frames, a few dozen extra launches, once per packed table):
         which table is faster depends on where the frames send the walks, which nothing in the forest's records tells.
         `auto_tune = False` on the evaluator, or a DecisionForest.tune() of one's own before, turns it off; a
         stream that is being captured into a hipGraph is never tuned on."""
@@ -389,7 +389,7 @@ class DecisionTreeEvaluator:
                 return
         except Exception:       # noqa: BLE001 -- (no torch runtime behind this evaluator: the host test double)
             return
-        done[s] = forest.tune(depth_images_in[0:min(16, n)], labels_reduce, scale_factor)
+        done[s] = forest.tune(depth_images_in[0:min(32, n)], labels_reduce, scale_factor)
 
     # -- composite: make_composite_labels_image ------------------------------------------------
     def make_composite_labels_image(self, images, dim_x, dim_y, labels_decision_tree, composite_image):

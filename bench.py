@@ -300,7 +300,7 @@ def main():
         tune5 = None
         if not a.unpacked:
             forest5.packed(1.0)
-            tune5 = tune_forest(forest5, depth5[0:min(8, F5)])
+            tune5 = tune_forest(forest5, depth5[0:min(16, F5)])
         for _ in range(warmup):
             ev.get_labels_forest(forest5, depth5, lab5)
         e5 = Events(rt, 2 * steps)
@@ -375,7 +375,7 @@ def main():
         tune5 = None
         if not a.unpacked:
             forest5.packed(1.0)
-            tune5 = tune_forest(forest5, depth5[0:min(8, F5)])      # (per rank, outside the timed regions; no collective inside)
+            tune5 = tune_forest(forest5, depth5[0:min(16, F5)])      # (per rank, outside the timed regions; no collective inside)
         mine = lab5.torch_bytes()           # uint8: every backend gathers bytes
         slabs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
 
@@ -496,7 +496,7 @@ def main():
     tune = None
     if not a.unpacked:
         forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
-        tune = tune_forest(forest, depth[0:min(16, F)])
+        tune = tune_forest(forest, depth[0:min(32, F)])
 
     # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
     def leg_cfg2(n1, forest_obj=None):
@@ -1065,7 +1065,7 @@ def main():
             fb_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_balanced", lambda: synth.forest(T, D, C, "balanced")))
             fb = rdf.DecisionForest.from_numpy(fb_np)
             fb.packed(1.0)
-            tune_b = tune_forest(fb, depth[0:min(16, F)])
+            tune_b = tune_forest(fb, depth[0:min(32, F)])
             res = leg_cfg2(200, fb)
             lab_b = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
             for _ in range(2):

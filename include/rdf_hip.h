@@ -168,7 +168,7 @@ int rdf_eval_forest_packed_stats(const uint16_t *depth, int n_img, int dim_x, in
  * one packed table on the current device (level > 0: deep blocks from that level on, 0: never, -1: forget -- the library's
  * default by forest size); rdf_forest_pack into the same memory forgets it.  rdf_forest_tune makes the choice by
  * measurement: it evaluates the caller's sample frames (device memory; results go to `labels_scratch`, uint16
- * [n_img][dim_y/r][dim_x/r]) with every candidate -- never, and each block root level -- four launches each, keeps the
+ * [n_img][dim_y/r][dim_x/r]) with every candidate -- never, and each block root level -- four to thirteen launches each, keeps the
  * fastest (the deep blocks must beat the heap-order records by 2 %: a tie goes to the default) and reports what it tried
  * (up to 12 entries in levels_tried / ms_tried, all three outputs nullable).  Synchronous.
  * Labels do not depend on the choice.  The process-wide knob rdf_set_deep_from (>= 0) overrides both.

@@ -263,7 +263,7 @@ def trainer_forest(rdf, frames_np, trees=4, depth=20, images=64, proposals=512, 
     del trainer, ds
     f = rdf.DecisionForest.from_numpy(forest_np)
     depth_dev = rdf.to_device(frames_np)
-    tune = f.tune(depth_dev[0:min(16, n)])
+    tune = f.tune(depth_dev[0:min(32, n)])
     ev = rdf.DecisionTreeEvaluator()
     out = rdf.DeviceArray(frames_np.shape, np.uint16).fill(65535)
     rt = rdf.get_runtime()

@@ -41,7 +41,7 @@ def main():
                 for C in (4, 3, 7, 8):
                     forest = rdf.DecisionForest.from_numpy(rdf.synth.forest(T, a.depth, C, topology))
                     forest.packed(1.0)
-                    tune = forest.tune(depth[0:16], labels_reduce=r)
+                    tune = forest.tune(depth[0:32], labels_reduce=r)
                     labels = rdf.DeviceArray((a.frames, 480 // r, 848 // r), np.uint16).fill(65535)
                     for _ in range(2):
                         ev.get_labels_forest(forest, depth, labels, r)

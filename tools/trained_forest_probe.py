@@ -65,7 +65,7 @@ def main():
     print(f"levels per (pixel, tree): {lv[valid].mean():.2f}; share of walks that reach level D-1: {(lv[valid] == a.depth).mean():.3f}")
     f = rdf.DecisionForest.from_numpy(forest_np)
     depth = rdf.to_device(frames)
-    res = f.tune(depth[0:16])
+    res = f.tune(depth[0:32])
     print("tune:", res)
     out = rdf.DeviceArray(frames.shape, np.uint16).fill(65535)
     lib = rdf.get_runtime().lib
