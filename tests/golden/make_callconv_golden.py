@@ -11,7 +11,9 @@ and the recorded sequences are the fixture.  tests/test_callconv.py replays the 
 on tests/fake_runtime.py and asserts the same sequence, wiring and scalars.
 
 This pins PLUMBING (fill order, layer order, filter wiring, (y, x) dims, argument order and types, launch geometry), not
-arithmetic: no kernel runs.  The fixture holds data only -- names, shapes and numbers -- no reference source text.
+the kernels' arithmetic: no kernel runs.  Two things in the fixture ARE outputs of the reference, because they are pure numpy
+and run as they are: the proposal generator (decision_tree.py:353-371: 40 proposals from a seeded global RNG, bit patterns and
+the RNG's position afterwards) and the dataset class's colour <-> id conversions (decision_tree.py:46-122).  The fixture holds data only -- names, shapes and numbers -- no reference source text.
 
     python3 tests/golden/make_callconv_golden.py        # rewrites tests/golden/callconv_v1.json
 """
@@ -251,6 +253,26 @@ def main():
         lf.run(depth_image, labels_image, s)
         fixture["scenarios"].append(dict(take(label + "_run"), config=cfg, depth_dims=list(dims), labels_reduce=r, scale_factor=s,
                                          forest_shapes={k: list(v) for k, v in shapes.items()}))
+    # ---- the reference's pure-numpy helpers, run as they are: these fixtures ARE outputs of the reference ----
+    # proposals (decision_tree.py:353-371): values bit for bit, and where the global RNG stands afterwards
+    np.random.seed(20211003)
+    arr = np.zeros((40, 5), np.float32)
+    ref.make_random_features(40, arr)
+    fixture["proposals"] = {"seed": 20211003, "n": 40, "float32_bits": arr.view(np.uint32).reshape(-1).tolist(),
+                            "next_random_after": float(np.random.random()).hex()}
+    # dataset bookkeeping and the colour <-> id conversions (decision_tree.py:46-122) on a tiny config (num_images = 0: no image blocks)
+    ddir = os.path.join(tmp, "ds") + os.sep
+    os.makedirs(ddir)
+    ds_cfg = {"img_dims": [6, 4], "num_images": 3, "id_to_color": {"1": [255, 0, 0, 255], "2": [0, 255, 0, 255], "3": [10, 20, 30, 255]}}
+    json.dump(ds_cfg, open(ddir + "config.json", "w"))
+    ds = ref.DecisionTreeDatasetConfig(ddir)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, 4, size=(2, 4, 6)).astype(np.uint16)
+    colors = ds.convert_ids_to_colors(ids)
+    back = ds.convert_colors_to_ids(colors[1])
+    fixture["dataset"] = {"config": ds_cfg, "num_classes": int(ds.num_classes()), "img_dims": list(ds.img_dims),
+                          "total_available_images": int(ds.total_available_images), "ids": ids.tolist(), "colors": colors.tolist(),
+                          "ids_back_from_colors_of_image_1": back.tolist(), "back_dtype": back.dtype.name, "colors_dtype": colors.dtype.name}
     out = os.path.join(HERE, "callconv_v1.json")
     json.dump(fixture, open(out, "w"), indent=1)
     print(f"wrote {out}: {len(fixture['scenarios'])} scenarios, {sum(len(s_['events']) for s_ in fixture['scenarios'])} events")

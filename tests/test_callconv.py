@@ -138,3 +138,33 @@ def test_layered_forest_issues_the_reference_sequence(rdf, host_runtime, tmp_pat
     del lib.trace[:]
     lf.run(depth_image, labels_image, run["scale_factor"])
     assert _my_events(lib.trace, roles) == _ref_events(label + "_run")
+
+
+def test_proposals_are_the_references_own_bit_for_bit(rdf):
+    """The reference's make_random_features (decision_tree.py:353-371) is pure numpy, so the fixture holds ITS output for a
+    seeded global RNG: both generators of this package -- the draw-by-draw loop and the bulk one the trainer uses -- give the same
+    float32 bits and leave the RNG where the reference leaves it."""
+    dt = __import__("importlib").import_module("3d-beats_amd.decision_tree")
+    fx = FIX["proposals"]
+    want = np.array(fx["float32_bits"], dtype=np.uint32).reshape(fx["n"], 5)
+    for gen in (dt.make_random_features_loop, dt.make_random_features):
+        np.random.seed(fx["seed"])
+        arr = np.zeros((fx["n"], 5), np.float32)
+        gen(fx["n"], arr)
+        assert np.array_equal(arr.view(np.uint32), want), gen.__name__
+        assert float(np.random.random()).hex() == fx["next_random_after"], gen.__name__
+
+
+def test_dataset_conversions_are_the_references_own(rdf, tmp_path):
+    """DecisionTreeDatasetConfig's bookkeeping and colour <-> id conversions against the reference class's own outputs."""
+    ds_mod = __import__("importlib").import_module("3d-beats_amd.dataset")
+    fx = FIX["dataset"]
+    (tmp_path / "config.json").write_text(json.dumps(fx["config"]))
+    ds = ds_mod.DecisionTreeDatasetConfig(str(tmp_path))
+    assert ds.num_classes() == fx["num_classes"] and list(ds.img_dims) == fx["img_dims"]
+    assert ds.total_available_images == fx["total_available_images"]
+    ids = np.array(fx["ids"], dtype=np.uint16)
+    colors = ds.convert_ids_to_colors(ids)
+    assert colors.dtype.name == fx["colors_dtype"] and np.array_equal(colors, np.array(fx["colors"], dtype=np.uint8))
+    back = ds.convert_colors_to_ids(np.array(fx["colors"], dtype=np.uint8)[1])
+    assert back.dtype.name == fx["back_dtype"] and back.tolist() == fx["ids_back_from_colors_of_image_1"]
