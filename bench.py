@@ -5,14 +5,17 @@ One "step" = one pass of the forest kernel over this rank's batch of synthetic 8
 (4 trees, depth 20, 4 classes -- BASELINE.json's metric config), frames already resident in HBM.
 Default workload: 128 frames per GPU per step (= config 4's shard, 1024 frames / 8 GPUs; it is
 config 2's frame x 128, half dense / half live-like), weak scaling: N GPUs evaluate N x 128 frames
-and every rank's label maps reach rank 0 over xGMI inside the timed region (copy-engine peer copies into rank 0's
-IPC-mapped buffer by default, an RCCL gather as the fallback: DESIGN.md section 6).
+and every rank's label maps reach rank 0 over xGMI inside the timed region: `value` is the RCCL gather's
+(torch.distributed.gather, overlapped with the next step's launch), two other transports are timed beside it and
+reported (copy-engine peer copies into rank 0's IPC-mapped ring; the kernels' own stores into it): DESIGN.md section 6.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  At N = 1 the same run also measures
+Rank 0's LAST stdout line is ONE compact JSON object (< 4 KB: the contract's keys, a flat `roofline`, `cpu_baseline`, one
+or two scalars per leg); the FULL result -- everything below -- goes to `bench_full.json` in the current directory
+(--full-json PATH) and, as one line, to stderr.  At N = 1 the same run also measures
   * `cfg2_single_frame` (ONE 848x480 frame per launch), `cfg3_layered_run` (LayeredDecisionForest.run),
   * `cfg5_shard` (config 5's per-GPU shard: 32 dense 1280x720 frames, 8 trees of depth 22, two frames checked against
     the oracle inside the run),
@@ -59,7 +62,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline levels "
-                    "then come from the committed profiles/r04_roofline_counters.json and say so)")
+                    "then come from the committed profiles/r0N_roofline_counters.json and say so)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the config-5 shard leg (2 GiB forest)")
     ap.add_argument("--cfg5-frames", type=int, default=32)
     ap.add_argument("--cfg5-trees", type=int, default=8, help="(tests shrink the config-5 forest)")
@@ -81,19 +84,23 @@ def parse():
                     help="tile schedule of the forest kernel: persistent workgroups on a device-side queue (default), "
                          "persistent with static striding, or one workgroup per tile (non-persistent: 8 %% slower alone, "
                          "but a concurrent RCCL kernel never waits for a free slot)")
-    ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl", "both"],
-                    help="how the label maps reach rank 0 at N>1: p2p = every rank copies its shard into rank 0's "
-                         "IPC-mapped ring with the copy engines (no CU involved); rccl = torch.distributed.gather on a "
-                         "compute stream that leaves 32 CUs to RCCL; "
-                         "auto (default) = time those two and `p2p direct stores` (every rank's kernel writes its labels straight "
-                         "into rank 0's ring, no copy) back to back, `value` is the fastest intact one's and `gather_modes` carries all "
-                         "(rccl alone if the buffer cannot be mapped); both = the same, but `value` is p2p's")
+    ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl", "both", "fastest"],
+                    help="how the label maps reach rank 0 at N>1: rccl = torch.distributed.gather (RCCL over xGMI) on a side stream, "
+                         "next to a compute stream that leaves 32 CUs to RCCL's kernels; p2p = every rank copies its shard into "
+                         "rank 0's IPC-mapped ring with the copy engines (no CU involved); "
+                         "auto (default) = `value` is the RCCL gather's (BASELINE's north_star: a single RCCL gather of the label "
+                         "maps), and the two alternatives -- copy engines, and `p2p direct stores` (every rank's kernel writes its "
+                         "labels straight into rank 0's ring, no copy) -- are timed back to back beside it and reported in "
+                         "`distributed.gather_modes` (the RCCL gather alone if the ring cannot be mapped); fastest = the same three, "
+                         "`value` is the fastest intact one's; both = the same, `value` is p2p's")
     ap.add_argument("--reserve-cus", type=int, default=-1, help="run the forest kernel on a stream that leaves this many CUs "
                     "(one per shader engine = 32) to RCCL's kernels; -1: 32 with the rccl gather, 0 otherwise (DESIGN.md section 6)")
     ap.add_argument("--fail-ipc-open-on-rank", type=int, default=None, help="test hook: that rank behaves as if it could not map "
                     "rank 0's receive buffer (the run must fall back to the RCCL gather and say why)")
     ap.add_argument("--force-distributed", action="store_true", help="take the N>1 code path (communicator, gather modes, CU-masked "
                     "stream, checksums, `distributed` block, config 5 on all ranks) even with ONE rank: puts the RCCL path on a one-GPU box")
+    ap.add_argument("--full-json", default=None, help="where rank 0 writes the FULL result (every leg, counter dumps, censuses); "
+                    "default: bench_full.json in the current directory.  The last stdout line is the compact summary of it (< 4 KB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1 (nccl = RCCL; gloo only to "
                     "rehearse the control flow with several ranks on one GPU)")
     return ap.parse_args()
@@ -155,11 +162,18 @@ def cached(name, make):
     return arr
 
 
+COMMITTED_COUNTERS = ("r05_roofline_counters.json", "r04_roofline_counters.json")     # newest first
+
+
 def committed_counters(key):
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r04_roofline_counters.json"))).get(key)
-    except Exception:
-        return None
+    for name in COMMITTED_COUNTERS:
+        try:
+            got = json.load(open(os.path.join(ROOT, "profiles", name))).get(key)
+        except Exception:
+            continue
+        if got:
+            return dict(got, _file=f"profiles/{name}")
+    return None
 
 
 def collect_counters(a, legs):
@@ -190,12 +204,169 @@ def roofline_for(leg, key, live, kernel_ms, alg_bytes, useful=None):
         com = committed_counters(key)
         if com:
             vals, kern = com.get("counters"), com.get("kernel")
-            src = "profiles/r04_roofline_counters.json (committed; this run collected none)"
+            src = f"{com.get('_file')} (committed; this run collected none)"
     r = roofline.model(vals, kernel_ms, alg_bytes, useful=useful)
     r["kernel"] = kern or "k_eval_forest"
     r["counters_source"] = src
     r["counters"] = {k: (int(v) if v == int(v) else round(v, 1)) for k, v in (vals or {}).items() if not k.startswith("_")}
     return r
+
+
+LINE_LIMIT = 4000       # bytes of the last stdout line (the driver's record keeps a short tail: round 4's 26-KB line came back unparsed)
+
+
+def _short_kernel(name):
+    """`void (anonymous namespace)::k_eval_forest<512, true, ...>(...)` -> `k_eval_forest<512,true,...>`"""
+    if not name:
+        return name
+    s = str(name).replace("void ", "").replace("(anonymous namespace)::", "")
+    s = s.split(">(")[0] + (">" if ">(" in s else "")
+    return s.replace(", ", ",")[:96]
+
+
+def compact_line(out, full_path=None):
+    """The ONE line the driver parses: the contract's keys, a flat `roofline`, `cpu_baseline` and one or two scalars per leg.
+    Everything else (levels, counter dumps, censuses, tune tables, prose) is in the full result (`full`, and on stderr)."""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+
+    def us(ms):
+        return None if ms is None else round(ms * 1e3, 1)
+
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = "classified Mpix/s on 848x480 depth frames (4 trees, depth 20); % of the bounding roofline level (roofline.bound; HBM: roofline.hbm_frac)"
+    for k in ("value_is", "value_mean", "ms_per_step_mean", "ms_per_step_median", "value_valid_pixels", "valid_pixel_share"):
+        if k in out:
+            line[k] = out[k]
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload"))[:260]}
+    for k in ("frames_per_gpu", "frame", "trees", "tree_depth", "classes", "topology", "forest_layout", "tile_schedule",
+              "pipeline_chunks", "sharding", "gather", "gather_overlap", "gather_check", "cus_left_to_rccl"):
+        if cfg.get(k) is not None:
+            line["config"][k] = cfg[k]
+    line["config"]["deep_from"] = g(cfg, "deep_level_table", "deep_from")
+
+    def flat_roofline(r):
+        if not isinstance(r, dict):
+            return None
+        lv = r.get("levels") or {}
+        f = {"bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"),
+             "frac": r.get("frac"), "useful_frac": r.get("useful_frac"), "traffic": r.get("traffic"),
+             "kernel": _short_kernel(r.get("kernel")), "kernel_ms": r.get("kernel_ms"),
+             "hbm_frac": g(lv, "hbm", "frac"), "hbm_gbs": g(lv, "hbm", "achieved"), "hbm_peak_gbs": g(lv, "hbm", "peak"),
+             "l2_l1_frac": g(lv, "l2_l1", "frac"), "l1_ta_frac": g(lv, "l1_ta", "frac"),
+             "ta_busy_frac_counter": g(lv, "l1_ta", "ta_busy_frac_counter"), "valu_frac": g(lv, "valu", "frac"),
+             "l2_hit_rate": r.get("l2_hit_rate"), "clock_ghz": r.get("clock_ghz"),
+             "algorithmic_bytes": g(r, "algorithmic", "bytes_per_launch"), "algorithmic_gbs": g(r, "algorithmic", "rate_gbs"),
+             "algorithmic_over_hbm_peak": g(r, "algorithmic", "over_hbm_peak"),
+             "copy_ceiling_gbs": g(r, "copy_ceiling", "value"),
+             "counters": ("live --pmc passes of this run" if "child passes" in str(r.get("counters_source"))
+                          else (str(r.get("counters_source"))[:80] if r.get("counters_source") else None))}
+        return {k: v for k, v in f.items() if v is not None or k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+
+    line["roofline"] = flat_roofline(out.get("roofline"))
+    line["bound"], line["hbm_frac"] = out.get("bound"), out.get("hbm_frac")
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {k: (str(cb[k])[:300] if k == "sample" else cb[k])
+                                for k in ("value", "unit", "cores", "kind", "sample", "parity_frames", "differing_pixels") if k in cb}
+        if cb.get("value"):
+            line["speedup_vs_cpu_baseline"] = round(out["value"] / cb["value"], 1)
+    # ---- one or two scalars per leg ----
+    legs = {
+        "value_balanced": out.get("value_balanced"),
+        "balanced_ms": g(out, "cfg2_balanced", "batch", "ms_per_step"),
+        "balanced_bound": g(out, "cfg2_balanced", "batch", "roofline", "bound"),
+        "balanced_frac": g(out, "cfg2_balanced", "batch", "roofline", "frac"),
+        "balanced_hbm_frac": g(out, "cfg2_balanced", "batch", "roofline", "levels", "hbm", "frac"),
+        "balanced_ta_busy": g(out, "cfg2_balanced", "batch", "roofline", "levels", "l1_ta", "ta_busy_frac_counter"),
+        "balanced_deep_from": g(out, "cfg2_balanced", "tune", "deep_from"),
+        "balanced_differing_pixels": g(out, "cfg2_balanced", "parity", "differing_pixels"),
+        "cfg2_us": us(g(out, "cfg2_single_frame", "kernel_ms")),
+        "cfg2_frac": g(out, "cfg2_single_frame", "roofline", "frac"),
+        "cfg2_balanced_us": us(g(out, "cfg2_balanced", "kernel_ms")),
+        "cfg2_trained_us": us(g(out, "cfg2_trained", "kernel_ms")),
+        "cfg3_us": us(g(out, "cfg3_layered_run", "ms_per_frame_wall")),
+        "cfg5_mpix": g(out, "cfg5_shard", "value"), "cfg5_ms": g(out, "cfg5_shard", "kernel_ms"),
+        "cfg5_bound": g(out, "cfg5_shard", "roofline", "bound"), "cfg5_frac": g(out, "cfg5_shard", "roofline", "frac"),
+        "cfg5_hbm_frac": g(out, "cfg5_shard", "roofline", "levels", "hbm", "frac"),
+        "cfg5_differing_pixels": g(out, "cfg5_shard", "parity", "differing_pixels"),
+        "cfg5_balanced_mpix": g(out, "cfg5_balanced", "value"), "cfg5_balanced_ms": g(out, "cfg5_balanced", "kernel_ms"),
+        "cfg5_balanced_bound": g(out, "cfg5_balanced", "roofline", "bound"),
+        "cfg5_balanced_frac": g(out, "cfg5_balanced", "roofline", "frac"),
+        "cfg5_balanced_hbm_frac": g(out, "cfg5_balanced", "roofline", "levels", "hbm", "frac"),
+        "cfg5_balanced_ta_busy": g(out, "cfg5_balanced", "roofline", "levels", "l1_ta", "ta_busy_frac_counter"),
+        "cfg5_balanced_deep_from": g(out, "cfg5_balanced", "tune", "deep_from"),
+        "cfg5_balanced_differing_pixels": g(out, "cfg5_balanced", "parity", "differing_pixels"),
+        "pcie_inclusive_mpix": g(out, "pcie_inclusive", "value"),
+        "pcie_pipelined_mpix": g(out, "pcie_inclusive_pipelined", "value"),
+        "unpacked_mpix": g(out, "unpacked", "value"),
+        "trained_batch_mpix": g(out, "cfg2_trained", "batch", "value"),
+        "trainer_forest_mpix": g(out, "cfg2_trainer_forest", "value"),
+        "hand_pipeline_us": g(out, "hand_pipeline", "us_per_hand_per_frame_as_hipgraph"),
+        "train_seconds": g(out, "train", "seconds"),
+        "cpu_baseline_numpy_mpix": g(out, "cpu_baseline_numpy", "value"),
+    }
+    line.update({k: v for k, v in legs.items() if v is not None})
+    errors = {k: str(v["error"])[:120] for k, v in out.items() if isinstance(v, dict) and "error" in v}
+    if errors:
+        line["leg_errors"] = errors
+    dd = out.get("distributed")
+    if isinstance(dd, dict):
+        line["distributed"] = {
+            "backend": dd.get("backend"), "rccl_ranks": dd.get("rccl_ranks"), "distinct_devices": dd.get("distinct_devices"),
+            "device_indices": [d_.get("device_index") for d_ in dd.get("devices") or []],
+            "kernel_only_ms": dd.get("kernel_only_ms"), "value_kernel_only": dd.get("value_kernel_only"),
+            "gather_modes": {n: {k: m.get(k) for k in ("ms_per_step", "value", "gather_check", "cus_left_to_rccl") if k in m}
+                             for n, m in (dd.get("gather_modes") or {}).items()},
+            "unavailable": {k: str(v)[:160] for k, v in (dd.get("unavailable") or {}).items()},
+            "total_seconds": dd.get("total_seconds")}
+    c5n = out.get("cfg5_all_ranks")
+    if isinstance(c5n, dict):
+        line["cfg5_all_ranks"] = {k: (str(c5n[k])[:160] if isinstance(c5n[k], str) else c5n[k])
+                                  for k in ("value", "unit", "ms_per_step", "value_kernel_only", "kernel_only_ms", "n_gpus", "gather",
+                                            "gather_check", "skipped", "error") if k in c5n}
+        ds = c5n.get("p2p_direct_stores")
+        if isinstance(ds, dict):
+            line["cfg5_all_ranks"]["direct_stores"] = {k: (str(v)[:120] if isinstance(v, str) else v) for k, v in ds.items()
+                                                       if k in ("value", "ms_per_step", "gather_check", "unavailable", "error")}
+    line["full"] = full_path
+    # a guarantee, not a hope: optional groups go first if the line is still too long
+    for drop in (None, "leg_errors", "cfg5_all_ranks", "legs", "distributed.unavailable", "cpu_baseline.sample", "config.workload"):
+        if drop == "legs":
+            for k in legs:
+                if k not in ("value_balanced", "cfg2_us", "cfg3_us", "cfg5_mpix", "cfg5_balanced_mpix", "cfg5_balanced_hbm_frac"):
+                    line.pop(k, None)
+        elif drop and "." in drop:
+            a_, b_ = drop.split(".")
+            if isinstance(line.get(a_), dict) and b_ in line[a_]:
+                line[a_][b_] = str(line[a_][b_])[:60] if isinstance(line[a_][b_], str) else {}
+        elif drop:
+            line.pop(drop, None)
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+    return line
+
+
+def emit(out, a):
+    """Rank 0: the full result to a side file and to stderr, its compact summary as the LAST stdout line."""
+    path = a.full_json or os.path.join(os.getcwd(), "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f)
+    except OSError as e:
+        print(f"could not write {path}: {e}", file=sys.stderr)
+        path = None
+    print(json.dumps(out), file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(out, path))
+    assert len(text) < LINE_LIMIT + 96, len(text)
+    print(text, flush=True)
 
 
 def main():
@@ -533,7 +704,7 @@ def main():
     # N>1, default: peer copies over xGMI by the copy engines (RCCL carries only the control plane); needs HIP IPC
     # between the ranks' processes, falls back to the RCCL gather if any rank cannot map rank 0's buffer
     peer, pg, peer_direct, pg_d, notes = None, None, None, None, {}      # notes: what was unavailable on this run and why (goes on the N > 1 line)
-    if multi and a.chunks == 0 and a.gather in ("auto", "p2p", "both"):
+    if multi and a.chunks == 0 and a.gather in ("auto", "fastest", "p2p", "both"):
         pg = dmod.PeerCopyGather(world, rank, F * H * W * 2, _fail_open_on_rank=a.fail_ipc_open_on_rank)
         if pg.ok:
             peer = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg)
@@ -541,7 +712,7 @@ def main():
             notes["p2p"] = "unavailable: " + "; ".join(f"rank {g}: {why}" for g, why in (pg.errors or {}).items())
         # the same ring a second time for the mode in which every rank's kernel writes its labels straight into rank 0's
         # memory (no copy at all): its own ring, so that the two modes' step counters do not meet
-        if pg.ok and a.gather in ("auto", "both"):
+        if pg.ok and a.gather in ("auto", "fastest", "both"):
             pg_d = dmod.PeerCopyGather(world, rank, F * H * W * 2)
             if pg_d.ok:
                 peer_direct = dmod.PeerCopyForestEvaluator(ev, forest, F, (H, W), pg_d, direct_stores=True)
@@ -656,7 +827,7 @@ def main():
             modes["p2p copy engines"] = (lambda: peer.step(depth, ring), peer.drain, None, 0, peer.result, True)
         if peer_direct is not None:
             modes["p2p direct stores"] = (lambda: peer_direct.step(depth, None), peer_direct.drain, None, 0, peer_direct.result, True)
-        if "p2p copy engines" not in modes or a.gather in ("rccl", "both", "auto"):
+        if "p2p copy engines" not in modes or a.gather in ("rccl", "both", "auto", "fastest"):
             modes["rccl gather"] = rccl_mode()
     torch.cuda.synchronize()
 
@@ -692,16 +863,19 @@ def main():
                 results[name]["ready_counters_ok"] = f"not read: {e}"[:120]
     if not results:
         raise SystemExit(f"every gather mode failed: {failed_modes}")
-    # `value` is the first mode's that ran (--gather p2p | rccl | both) or, with --gather auto, the faster one's: nobody has
-    # seen either mode cross two GPUs before the driver's run, so the default times both (K steps each) and says so
+    # `value` is the RCCL gather's by default (north_star: "a single RCCL gather of the label maps over xGMI"); the other
+    # transports are timed beside it and reported (distributed.gather_modes).  --gather fastest: the fastest intact mode's;
+    # p2p | rccl | both: the first mode's that ran.  A mode whose label maps did not arrive intact is never `value`.
     primary = next(iter(results))
-    if a.gather == "auto" and len(results) > 1:
-        # (`elapsed` is the MAX over ranks and the check's verdict is broadcast below: the same choice on every rank; a mode
-        # whose label maps did not arrive intact is never `value`)
+    if a.gather in ("auto", "fastest") and len(results) > 1:
+        # (`elapsed` is the MAX over ranks and the check's verdict is broadcast below: the same choice on every rank)
         verdicts = [{n: r["gather_check"] for n, r in results.items()}]
         dist.broadcast_object_list(verdicts, src=0)
         intact = [n for n in results if verdicts[0].get(n) == "ok"] or list(results)
-        primary = min(intact, key=lambda n: results[n]["elapsed"])
+        if a.gather == "auto" and "rccl gather" in intact:
+            primary = "rccl gather"
+        else:
+            primary = min(intact, key=lambda n: results[n]["elapsed"])
     elapsed, kern_ms = results[primary]["elapsed"], results[primary]["kern_ms"]
     if not multi:
         assert np.array_equal(labels.get(), scratch.get()), "timed path and stats path disagree"
@@ -1141,7 +1315,7 @@ def main():
     if rank == 0:
         if multi:
             out["distributed"]["total_seconds"] = round(time.perf_counter() - t_main, 1)    # this process, start to line
-        print(json.dumps(out), flush=True)
+        emit(out, a)
     if multi:
         dist.barrier()
         for ring in (pg, pg_d):                 # unmap on the peers before rank 0 frees the buffer
