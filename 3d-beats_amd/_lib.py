@@ -29,6 +29,9 @@ SIGNATURES = {
     "rdf_eval_forest_packed_stats": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                                               _c_int, _c_void_p, _c_void_p]),
     "rdf_forest_set_deep_from": (_c_int, [_c_void_p, _c_int]),
+    "rdf_forest_info": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int),
+                                 ctypes.POINTER(_c_float)]),
+    "rdf_forest_forget": (_c_int, [_c_void_p]),
     "rdf_forest_tune": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                                  _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "rdf_eval_forest_packed": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
@@ -109,10 +112,11 @@ SIGNATURES = {
     "rdf_event_destroy": (_c_int, [_c_void_p]),
     "rdf_stream_synchronize": (_c_int, [_c_void_p]),
     "rdf_abi_version": (_c_int, []),
+    "rdf_build_id": (ctypes.c_char_p, []),
     "rdf_error_string": (ctypes.c_char_p, [_c_int]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 
@@ -141,8 +145,29 @@ def load():
         fn.argtypes = args
     if lib.rdf_abi_version() != ABI_VERSION:
         raise RdfError(f"librdf_hip.so ABI {lib.rdf_abi_version()} != expected {ABI_VERSION}; rebuild")
+    check_build_id(lib, path)
     _lib = lib
     return lib
+
+
+def check_build_id(lib, path):
+    """The library must have been built from the sources that sit next to it: same ABI number, yesterday's kernels would
+    otherwise pass every check.  RDF_HIP_LIBRARY (an alternate build for a timing experiment) and a deployment without
+    sources are exempt; RDF_ALLOW_STALE_LIBRARY=1 turns the refusal into a warning."""
+    got = lib.rdf_build_id()
+    got = got.decode() if isinstance(got, bytes) else str(got)
+    if os.environ.get("RDF_HIP_LIBRARY") or not _build.sources_present():
+        return got
+    want = _build.source_id()
+    if got != want:
+        msg = (f"{path} was built from other sources (build id {got}, sources {want}): rebuild it "
+               "(python __graft_entry__.py build).")
+        if os.environ.get("RDF_ALLOW_STALE_LIBRARY") == "1":
+            import warnings
+            warnings.warn(msg)
+        else:
+            raise RdfError(msg)
+    return got
 
 
 def check(lib, code, what):

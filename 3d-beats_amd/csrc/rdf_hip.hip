@@ -123,7 +123,10 @@ struct PackInfo {
     uint32_t exact_nodes;   // nodes flagged kFlagExact
     float scale;            // the scale_factor the table was packed for
     uint32_t magic;         // kPackMagic once k_pack has run
-    uint32_t pad[29];
+    uint32_t deep_choice;   // which table serves the deep levels, chosen for THIS table (rdf_forest_set_deep_from / rdf_forest_tune):
+                            // 0 = no choice made, 1 + level otherwise (1 = heap-order records).  It travels with the table: a process that
+                            // maps or copies a tuned table (and every later evaluation in this one) finds the choice without tuning again
+    uint32_t pad[28];
 };
 constexpr uint32_t kPackMagic = 0x52444634u;   // "RDF4"
 // Last-level record, 64 bytes (forests of up to four classes): the hot record of a node of level D-1 and the PDFs of
@@ -161,11 +164,6 @@ static_assert(sizeof(NodeRec16) == 16 && sizeof(PackInfo) == 128 && sizeof(LastL
 // of level D - 1 has two leaves: k_pack leaves both facts in the trailer {1 + deepest level with an exact node,
 // nodes of level D - 1 that are not plain two-leaf nodes}.
 __host__ __device__ inline int deep_last_levels(int cpad) { return cpad == 4 ? 2 : 1; }
-__host__ __device__ inline bool deep_possible(int n_trees, int max_depth, int cpad)
-{
-    // (a lane's byte offset inside the blocks of one root level is heap index x 128 in 32 bits: root levels up to 22)
-    return n_trees >= 1 && (cpad == 4 || cpad == 8) && max_depth >= 5 && max_depth <= 24;
-}
 // lines of every block level whose root level is below R (R, Lmin members of the series R0 - 3 i)
 __host__ __device__ inline size_t deep_lines_before(int n_trees, int R, int Lmin)
 {
@@ -176,6 +174,19 @@ __host__ __device__ inline size_t deep_total_lines(int n_trees, int max_depth, i
     const int R0 = max_depth - deep_last_levels(cpad);
     return deep_lines_before(n_trees, R0, R0 % 3) + ((size_t)n_trees << R0);
 }
+// A lane addresses its block as {wave-uniform 64-bit base of its tree's blocks of the root level} + {32-bit byte offset}: a
+// walking lane's offset is its heap index x 128 (root levels up to 23), a lane whose walk has ended points at the table's
+// all-zero line BEHIND the last block with the offset (zero line - base), and the base of tree 0 lies up to 2^R lines in front
+// of the level's first block (the 2^R of a heap index folded in).  So a forest gets deep blocks only while
+// (all lines + 2^R0) x 128 stays below 2^32: T4/D24 (2.5 GB of blocks) and T6/D24 (3.7 GB) do, T8/D24 (4.9 GB) does not and is
+// walked from the heap-order records -- round 4 let the offset wrap there (labels stayed right, finished lanes fetched live
+// blocks and probed far from their pixel).
+__host__ __device__ inline bool deep_possible(int n_trees, int max_depth, int cpad)
+{
+    if (!(n_trees >= 1 && (cpad == 4 || cpad == 8) && max_depth >= 5 && max_depth <= 24)) return false;
+    const int R0 = max_depth - deep_last_levels(cpad);
+    return ((deep_total_lines(n_trees, max_depth, cpad) + ((size_t)1 << R0)) << 7) < ((size_t)1 << 32);
+}
 
 struct EvalArgs {
     const uint16_t *depth;
@@ -185,13 +196,6 @@ struct EvalArgs {
     uint16_t *labels;
     unsigned long long *stats;
     int stats_wide;        // stats holds 8 counters (rdf_eval_forest_packed_stats), not 3
-#ifdef RDF_EXPERIMENT_REFILL_BOUND
-    // timing experiment (tools/refill_bound_gpu.py, not in the product build): what a wave's level loop would cost if lanes
-    // were refilled for free -- pass 1 records, per wave slot (image row x 64-column chunk), the sum and count of its lanes'
-    // longest walks; pass 2 runs every wave's level loop for the MEAN of them only (labels are then wrong)
-    unsigned int *x_sum, *x_cnt;
-    const unsigned char *x_limit;
-#endif
     unsigned int *sched;   // queue slot, or nullptr for static round-robin tiles
     uint32_t n_tiles;      // n_img * tiles_x * tiles_y
     uint32_t tiles_x;      // ceil(Wl / 64)
@@ -746,21 +750,11 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                     const bool fast_levels = PACKED || K > 0;
                     if (fast_levels) set_round_down(rcp_s);
 
-#ifdef RDF_EXPERIMENT_REFILL_BOUND
-                    const uint32_t x_slot = (img * (uint32_t)a.Hl + (uint32_t)ly) * a.tiles_x + tx;
-                    const int x_levels = a.x_limit ? min(walk_levels, (int)a.x_limit[x_slot]) : walk_levels;
-                    int x_len = 0;
-#else
-                    const int x_levels = walk_levels;
-#endif
-                    for (int j = 0; j < x_levels; ++j) {
+                    for (int j = 0; j < walk_levels; ++j) {
                         bool any = false;
 #pragma unroll
                         for (int k = 0; k < GROUP; ++k) any |= (int)h[k] > 0;
                         if (!__any(any)) break;
-#ifdef RDF_EXPERIMENT_REFILL_BOUND
-                        x_len = any ? j + 1 : x_len;
-#endif
 
                         const bool in_lds = j < K;
                         float df_e = df;     // (a copy the mode switches tie)
@@ -883,12 +877,6 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             h[k] = walking ? next : h[k];
                         }
                     }
-#ifdef RDF_EXPERIMENT_REFILL_BOUND
-                    if (a.x_sum) {
-                        atomicAdd(a.x_sum + x_slot, (unsigned)x_len);
-                        atomicAdd(a.x_cnt + x_slot, 1u);
-                    }
-#endif
                     // ---- deep blocks: the levels from a.deep_from on, one tree after the other.  A lane loads the seven records of
                     // its block -- one 128-byte line -- at once: one fill, and the L1 and L2 do not keep a line from one level
                     // to the next (a record fetched later from the same line was a second fetch from beyond L2 every time:
@@ -944,14 +932,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                 for (int w = 0; w < W; ++w) {
                                     const int tk = min(kb + k0 + w, a.T - 1);
                                     const size_t base_at = (deep_lines_before(a.T, R, Lmin) + ((size_t)tk << R) - ((size_t)1 << R)) << 7;
+                                    // (zero line - base fits 32 bits for every forest deep_possible() admits)
                                     const uint32_t off = (int)hk[w] > 0 ? hk[w] << 7 : (uint32_t)(zero_at - base_at);
                                     const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.deep) + base_at + off);
-#ifdef RDF_EXPERIMENT_ONE_LOAD_PER_BLOCK
-                                    // timing experiment (labels wrong): what a block would cost if ONE access per lane brought it --
-                                    // the floor under any scheme that loads a line cooperatively (profiles/r04_deep_variants.txt)
-#pragma unroll
-                                    for (int i = 0; i < 7; ++i) q[i][w] = bp[0];
-#else
                                     // (five to eight classes, last block {node, pad, left PDF, right PDF}: records 1 and 6 hold nothing)
                                     const bool short_block = CMAX == 8 && R == R0;
 #pragma unroll
@@ -959,7 +942,6 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                                         if (CMAX == 8 && (i == 1 || i == 6) && short_block) q[i][w] = make_uint4(0u, 0u, 0u, 0u);
                                         else q[i][w] = bp[i];
                                     }
-#endif
                                     if (STATS && c0 == 0) st_blk += (int)hk[w] > 0 ? 1u : 0u;     // (a block is a line of its own)
                                 }
                                 // (issued together -- the line is filled once -- before anything is decoded)
@@ -1812,25 +1794,14 @@ int launch_deep(bool compact, const EvalArgs &a, int lds_bytes, int cus, hipStre
     return a.cpad == 4 ? launch_deep_c<BLOCK, 4>(compact, a, lds_bytes, cus, st) : launch_deep_c<BLOCK, 8>(compact, a, lds_bytes, cus, st);
 }
 
-// Where the deep blocks take over by default (no knob, no per-forest choice): 0 = never.  Measured on forests whose deep
-// levels are occupied (synth's balanced topology; DESIGN.md section 4, "deep blocks"): T4/D20 on the bench batch 11.2 ms with
-// the heap-order table, 9.1 / 7.8 / 7.8 / 9.8 ms with blocks from level 9 / 12 / 15 / 18; T8/D22 on config 5's shard
-// 38.4 ms against 25.8 / 24.8 / 24.9 / 27.0 ms from level 8 / 11 / 14 / 17.  So: forests whose hot records exceed what the L2s
-// and the Infinity Cache serve at the L1's pace (32 MB and more) take the blocks from the deepest root level that holds at
-// most 512 KB of heap-order records (an XCD's L2 keeps the levels above it).  A forest whose deep levels are NOT occupied
-// -- synth's "full" topology draws thresholds that send most pixels one way, its deep working set is a few megabytes --
-// is served faster by the heap-order table (3.9 against 5.9 ms): nothing in the records tells the two apart, which is
-// what rdf_forest_tune is for (it times both on the caller's frames and remembers the winner for that packed forest).
-int deep_default(int n_trees, int max_depth, int cpad, int K, bool big)
-{
-    if (!big) return 0;
-    if (((size_t)n_trees << max_depth) * sizeof(NodeRec16) < ((size_t)32 << 20)) return 0;
-    const int R0 = max_depth - deep_last_levels(cpad);
-    int from = R0;
-    while (from - 3 >= K && from - 3 >= 1) from -= 3;        // the smallest root level below LDS ...
-    while (from + 3 <= R0 && ((size_t)n_trees << (from + 3)) * sizeof(NodeRec16) <= ((size_t)512 << 10)) from += 3;   // ... up to 512 KB of records
-    return from;
-}
+// Where the deep blocks take over when nothing was chosen (no knob, no rdf_forest_set_deep_from / rdf_forest_tune for the table):
+// NEVER -- the heap-order records, round 3's walk.  Round 4 switched forests of 32 MB of hot records and more to the blocks by
+// size alone; that default was slower on two of the three kinds of forest measured (synth's "full" topology 5.9 against 3.9 ms,
+// the trainer's own forest 0.83 against 0.70 ms: profiles/r04_trained_forest_probe.txt) and faster only where the deep levels
+// are occupied (balanced topology: 7.8 against 11.2 ms).  Nothing in the records tells the kinds apart, so the blocks are taken
+// only where a measurement on the caller's frames chose them: rdf_forest_tune, or rdf_forest_set_deep_from with a level found
+// that way (a good first guess for an occupied forest: the deepest root level that still holds <= 512 KB of heap-order records).
+constexpr int kUntunedDeepFrom = 0;
 
 // What the host knows about a packed table, per (device, table): the per-forest choice of the deep-level table
 // (rdf_forest_set_deep_from / rdf_forest_tune; level, 0 = never, -1 = none made) and what rdf_forest_pack found -- how many
@@ -1839,6 +1810,7 @@ struct PackedState {
     int deep_from = -1;
     int exact_nodes = -1;      // -1: not read back yet
     float scale = 1.0f;
+    const void *info_dev = nullptr;     // the table's info block in device memory, once known (the choice is written through to it)
 };
 std::map<std::pair<int, const void *>, PackedState> g_packed;
 
@@ -1866,7 +1838,7 @@ int packed_info(const void *packed, const void *info_dev, void *stream, PackedSt
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
-        return RDF_ERR_BAD_ARG;     // a table's first evaluation cannot be recorded into a graph: evaluate it once before capturing
+        return RDF_ERR_CAPTURE;     // a table's first evaluation cannot be recorded into a graph: evaluate it once before capturing
     PackInfo host;
     hipError_t e = hipMemcpyAsync(&host, info_dev, sizeof(host), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
@@ -1876,7 +1848,33 @@ int packed_info(const void *packed, const void *info_dev, void *stream, PackedSt
     PackedState &st = g_packed[key];
     st.exact_nodes = (int)(host.exact_nodes > 0x7FFFFFFFu ? 0x7FFFFFFFu : host.exact_nodes);
     st.scale = host.scale;
+    st.info_dev = info_dev;
+    // the choice the table carries (made by whoever tuned it, in this process or another), unless this process made one since
+    if (st.deep_from < 0 && host.deep_choice != 0u && host.deep_choice <= 31u) st.deep_from = (int)host.deep_choice - 1;
     *out = st;
+    return RDF_OK;
+}
+
+// The per-table choice in the host's map only (rdf_forest_tune's candidates), and written through to the table's info block
+// (rdf_forest_set_deep_from: a synchronous 4-byte copy -- choosing is a load-time action).
+int set_deep_choice(const void *packed, int level, bool write_through)
+{
+    if (!packed) return RDF_ERR_NULL_PTR;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    const void *info_dev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        PackedState &st = g_packed[std::make_pair(dev, packed)];
+        st.deep_from = level < 0 ? -1 : level;
+        info_dev = st.info_dev;
+    }
+    if (write_through && info_dev) {
+        const uint32_t word = level < 0 ? 0u : (uint32_t)(level > 30 ? 30 : level) + 1u;
+        const hipError_t e = hipMemcpy(reinterpret_cast<char *>(const_cast<void *>(info_dev)) + offsetof(PackInfo, deep_choice), &word,
+                                       sizeof(word), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return (int)e;
+    }
     return RDF_OK;
 }
 
@@ -1928,17 +1926,13 @@ static size_t info_offset(int n_trees, int max_depth, int n_classes)
 }
 
 
-#ifdef RDF_EXPERIMENT_REFILL_BOUND
-unsigned int *g_x_sum = nullptr, *g_x_cnt = nullptr;
-const unsigned char *g_x_limit = nullptr;
-#endif
 Knob g_halo{-1};
 Knob g_lds_levels{-1};
 Knob g_tree_waves{-1};
 Knob g_stage_vec{-1};
 Knob g_rows_per_wave{0};
 Knob g_force_exact{0};
-Knob g_deep_from{-1};                           // -1: deep blocks by forest size (eval_common); 0: never; > 0: from this level on (rounded up to a block root)
+Knob g_deep_from{-1};                           // -1: the table's own choice (eval_common); 0: never; > 0: from this level on (rounded up to a block root)
 Knob g_last_level_table{-1};                    // -1: level D-1 from the last-level table when it is usable and the forest uses half of that level; 1: whenever usable; 0: never
 
 // What eval_common works out before it launches: the kernel arguments (without a queue slot), the dynamic LDS and the
@@ -2121,14 +2115,14 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         a.last_level_min = (uint32_t)((((unsigned long long)n_trees << (max_depth - 1)) * (unsigned long long)(pct < 0 ? 0 : pct > 100 ? 100 : pct)) / 100u);
     }
     // deep blocks (k_eval_forest<..., DEEP>): from which root level on.  The knob or RDF_DEEP_FROM names a level (rounded up
-    // to a block root, and never inside the levels LDS holds); the default is in deep_default().
+    // to a block root, and never inside the levels LDS holds); nothing chosen: kUntunedDeepFrom.
     bool deep_launch = false;
     if (packed && !tw && deep_bytes(n_trees, max_depth, n_classes) != 0) {
         const int R0 = max_depth - deep_last_levels(a.cpad);
         const int knob = g_deep_from;
         int from = knob >= 0 ? knob : env_int("RDF_DEEP_FROM", -1);      // process-wide knob first,
         if (from < 0) from = forest_deep_choice(packed);                 // then what was chosen for this packed forest,
-        if (from < 0) from = deep_default(n_trees, max_depth, a.cpad, K, big);   // then the default by forest size
+        if (from < 0) from = kUntunedDeepFrom;                           // else the heap-order records
         if (from > 0) {
             if (from < K) from = K;
             if (from > R0) from = R0;
@@ -2155,9 +2149,6 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     }
 
     a.sched = sched_slot(stream);
-#ifdef RDF_EXPERIMENT_REFILL_BOUND
-    a.x_sum = g_x_sum; a.x_cnt = g_x_cnt; a.x_limit = g_x_limit;
-#endif
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int cus = usable_cus(st, di.cus);   // a CU-masked stream holds fewer persistent workgroups
@@ -2297,11 +2288,30 @@ int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_
 
 int rdf_forest_set_deep_from(const void *packed, int level)
 {
+    return set_deep_choice(packed, level, true);
+}
+
+int rdf_forest_info(const void *packed, int n_trees, int max_depth, int n_classes, void *stream, int *deep_from, int *exact_nodes,
+                    float *scale)
+{
+    if (!packed) return RDF_ERR_NULL_PTR;
+    if (n_trees < 1 || max_depth < 1 || max_depth > 27 || n_classes < 0) return RDF_ERR_BAD_ARG;
+    PackedState ps;
+    const int rc = packed_info(packed, reinterpret_cast<const char *>(packed) + info_offset(n_trees, max_depth, n_classes), stream, &ps);
+    if (rc != RDF_OK) return rc;
+    if (deep_from) *deep_from = ps.deep_from;
+    if (exact_nodes) *exact_nodes = ps.exact_nodes;
+    if (scale) *scale = ps.scale;
+    return RDF_OK;
+}
+
+int rdf_forest_forget(const void *packed)
+{
     if (!packed) return RDF_ERR_NULL_PTR;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_sched_mu);
-    g_packed[std::make_pair(dev, packed)].deep_from = level < 0 ? -1 : level;
+    g_packed.erase(std::make_pair(dev, packed));
     return RDF_OK;
 }
 
@@ -2328,7 +2338,7 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
     int best = 0, rc = RDF_OK;
     float best_ms = 0.f, heap_ms = 0.f;
     for (int c = 0; c < n_cand && rc == RDF_OK; ++c) {
-        rc = rdf_forest_set_deep_from(packed, cand[c]);
+        rc = set_deep_choice(packed, cand[c], false);
         float ms_min = 0.f;
         int reps = 4;                                            // one warm-up, then the fastest of three ... twelve launches:
         for (int rep = 0; rep < reps && rc == RDF_OK; ++rep) {   // short launches are repeated until ~10 ms have been timed
@@ -2357,7 +2367,7 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != RDF_OK) {
-        rdf_forest_set_deep_from(packed, -1);
+        set_deep_choice(packed, -1, false);
         return rc;
     }
     if (n_tried) *n_tried = n_cand;
@@ -2753,14 +2763,15 @@ int rdf_event_elapsed_ms(void *start, void *stop, float *ms)
 int rdf_event_destroy(void *event) { return (int)hipEventDestroy(reinterpret_cast<hipEvent_t>(event)); }
 int rdf_stream_synchronize(void *stream) { return (int)hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)); }
 
-#ifdef RDF_EXPERIMENT_REFILL_BOUND
-extern "C" void rdf_experiment_refill_bound(unsigned int *sum, unsigned int *cnt, const unsigned char *limit)
-{
-    g_x_sum = sum; g_x_cnt = cnt; g_x_limit = limit;
-}
-#endif
 
 int rdf_abi_version(void) { return RDF_ABI_VERSION; }
+
+#ifndef RDF_BUILD_ID
+#define RDF_BUILD_ID "unknown"
+#endif
+// (the marker in front lets a build script find the id in the file without loading it)
+static const char kBuildIdMarker[] = "rdf-build-id:" RDF_BUILD_ID;
+const char *rdf_build_id(void) { return kBuildIdMarker + 13; }
 
 const char *rdf_error_string(int code)
 {
@@ -2770,6 +2781,7 @@ const char *rdf_error_string(int code)
     case RDF_ERR_NULL_PTR: return "rdf: required pointer is NULL";
     case RDF_ERR_TOO_LARGE: return "rdf: call addresses >= 2^31 pixels (or a frame is 2^23 pixels wide / 2^24 high or more), split the batch";
     case RDF_ERR_NO_DEVICE: return "rdf: no usable HIP device";
+    case RDF_ERR_CAPTURE: return "rdf: the stream is being captured into a hipGraph and this call needs a synchronous step (a packed table's first evaluation reads its info block back: evaluate it once, or pack it, before capturing)";
     case RDF_ERR_BUILD: return "rdf: this build of the library breaks an assumption of its own kernels (static LDS in a forest kernel); rebuild it";
     default: break;
     }

@@ -15,7 +15,9 @@ library's business.  The trainer half of the reference module (decision_tree.py:
 make_random_features and DecisionTreeTrainer; the dataset reader lives in dataset.py.
 """
 import json
+import logging
 import os
+import time
 
 import numpy as np
 
@@ -25,6 +27,7 @@ from .engine.buffer import GpuBuffer
 from .util import MAX_UINT16  # noqa: F401  (re-exported like the reference module)
 
 _PIX_LIMIT = (1 << 31) - 1  # one C-ABI call addresses < 2^31 depth pixels (RDF_ERR_TOO_LARGE)
+_log = logging.getLogger("rdf_hip")
 
 
 class DecisionTree:
@@ -93,6 +96,8 @@ class DecisionForest:
         nbytes = int(lib.rdf_forest_packed_bytes(int(self.num_trees), int(self.max_depth), int(self.num_classes)))
         if nbytes == 0:
             return None
+        if hit is not None and hit[1].nbytes != nbytes:
+            self._forget(hit[1])
         buf = hit[1] if (hit is not None and hit[1].nbytes == nbytes) else DeviceArray((nbytes,), np.uint8)
         _lib.check(lib, lib.rdf_forest_pack(device_ptr(self.forest_cu), int(self.num_trees), int(self.max_depth),
                                             int(self.num_classes), s, buf.ptr, rt.stream()), "rdf_forest_pack")
@@ -100,10 +105,66 @@ class DecisionForest:
         self.__dict__.setdefault("_tuned", {}).pop(s, None)      # a new table: its deep-level choice is made again
         return buf
 
+    @staticmethod
+    def _forget(buf):
+        """The library keeps what it knows about a packed table per (device, address): told before the memory goes away, so that
+        another table that later lands on the same address is read afresh (rdf_forest_forget)."""
+        try:
+            lib = get_runtime().lib
+            if hasattr(lib, "rdf_forest_forget"):
+                lib.rdf_forest_forget(buf.ptr)
+        except Exception:       # noqa: BLE001 -- (interpreter shutdown, or a runtime that is already gone)
+            pass
+
+    def __del__(self):
+        for _, buf in list(getattr(self, "_packed", {}).values()):
+            self._forget(buf)
+
+    def packed_bytes(self, scale_factor=1.):
+        """The packed table for `scale_factor` as host bytes (numpy uint8), deep-level choice included: pack and tune once where
+        the model is built, ship the table, `adopt_packed` it where the model runs -- no repack, no tuning there.  Not in the
+        reference."""
+        buf = self.packed(scale_factor)
+        return None if buf is None else buf.get().copy()
+
+    def adopt_packed(self, table_bytes, scale_factor=1.):
+        """Takes a table `packed_bytes` produced for THIS forest (same trees / depth / classes, same forest_cu contents, same
+        scale) instead of packing: the table is uploaded, the library reads its info block at the first evaluation (a table
+        that rdf_forest_pack of this library version did not write is refused there) and finds the deep-level choice in it."""
+        s = float(np.float32(scale_factor))
+        rt = get_runtime()
+        lib = rt.lib
+        nbytes = int(lib.rdf_forest_packed_bytes(int(self.num_trees), int(self.max_depth), int(self.num_classes)))
+        table_bytes = np.ascontiguousarray(table_bytes, dtype=np.uint8).reshape(-1)
+        assert table_bytes.size == nbytes, f"packed table of {table_bytes.size} bytes, this forest's is {nbytes}"
+        hit = self._packed.get(s)
+        buf = hit[1] if (hit is not None and hit[1].nbytes == nbytes) else DeviceArray((nbytes,), np.uint8)
+        self._forget(buf)               # whatever the library knew about this address
+        buf.set(table_bytes)
+        self._packed[s] = ((id(self.forest_cu), self.forest_cu.version), buf)
+        self.__dict__.setdefault("_tuned", {}).pop(s, None)
+        return buf
+
+    def deep_from(self, scale_factor=1.):
+        """The deep-level choice the packed table of `scale_factor` carries: a level, 0 (heap-order records), or None when
+        nothing was chosen for it (rdf_forest_info; reads the table's info block if the library has not seen the table yet)."""
+        import ctypes
+        hit = self._packed.get(float(np.float32(scale_factor)))
+        rt = get_runtime()
+        lib = rt.lib
+        if hit is None or not hasattr(lib, "rdf_forest_info"):
+            return None
+        level = ctypes.c_int(-1)
+        _lib.check(lib, lib.rdf_forest_info(hit[1].ptr, int(self.num_trees), int(self.max_depth), int(self.num_classes), rt.stream(),
+                                            ctypes.byref(level), None, None), "rdf_forest_info")
+        return None if level.value < 0 else int(level.value)
+
     def tune(self, depth_images_in, labels_reduce=1, scale_factor=1.):
         """Chooses, by measurement on `depth_images_in` (device array [N, H, W] of representative frames), which table
         serves this packed forest's deep levels -- heap-order records or the deep blocks, and from which level
-        (rdf_forest_tune, include/rdf_hip.h) -- and remembers it for the packed table of `scale_factor`.  Labels do
+        (rdf_forest_tune, include/rdf_hip.h) -- and writes the choice into the packed table of `scale_factor`, where every
+        later evaluation (and `packed_bytes` / `adopt_packed`) finds it.  The documented flow: `DecisionForest.load(...)`,
+        then ONE `tune(sample)` at load time; a table nobody tuned is walked from the heap-order records.  Labels do
         not depend on the choice.  Not in the reference.  Returns {"deep_from": level or 0, "tried": {level: ms}}."""
         import ctypes
         packed = self.packed(scale_factor)
@@ -367,14 +428,19 @@ class DecisionTreeEvaluator:
     # forests from this size on (hot records) may or may not be served better by the deep blocks: see DecisionForest.tune
     AUTO_TUNE_HOT_BYTES = 32 << 20
     AUTO_TUNE_PIXELS = 8 * 480 * 848
+    AUTO_TUNE_SAMPLE_FRAMES = 32
+    AUTO_TUNE_SAMPLE_PIXELS = 1 << 26       # the sample is one C-ABI call (< 2^31 pixels) and its scratch label map stays small
 
     def _maybe_tune(self, forest, depth_images_in, labels_reduce, scale_factor):
-        """The first batch-sized evaluation of a big packed forest chooses its deep-level table by measurement
-        (DecisionForest.tune on up to 32 of the batch's own frames, a few dozen extra launches, once per packed table):
-        which table is faster depends on where the frames send the walks, which nothing in the forest's records tells.
-        `auto_tune = False` on the evaluator, or a DecisionForest.tune() of one's own before, turns it off; a
-        stream that is being captured into a hipGraph is never tuned on."""
-        if not getattr(self, "auto_tune", True) or not hasattr(forest, "tune") or not hasattr(self._lib, "rdf_forest_tune"):
+        """Safety net for callers that never tune: the first batch-sized evaluation of a big packed forest WHOSE TABLE CARRIES NO
+        CHOICE makes it by measurement (DecisionForest.tune on up to 32 of the batch's own frames: a few dozen extra launches and
+        a scratch label map, once per packed table), logs one line (logger "rdf_hip") and goes on; a failure there is logged and
+        the evaluation proceeds with the heap-order records.  It never fires for a table that was tuned (`tune()` at load time:
+        the documented flow), adopted with a choice inside (`adopt_packed`), or set by hand; `RDF_AUTO_TUNE=0` in the environment
+        or `auto_tune = False` on the evaluator turns it off; a stream being captured into a hipGraph is never tuned on."""
+        if not getattr(self, "auto_tune", True) or os.environ.get("RDF_AUTO_TUNE", "1") == "0":
+            return
+        if not hasattr(forest, "tune") or not hasattr(self._lib, "rdf_forest_tune"):
             return
         s = float(np.float32(scale_factor))
         done = forest.__dict__.setdefault("_tuned", {})
@@ -389,7 +455,22 @@ class DecisionTreeEvaluator:
                 return
         except Exception:       # noqa: BLE001 -- (no torch runtime behind this evaluator: the host test double)
             return
-        done[s] = forest.tune(depth_images_in[0:min(32, n)], labels_reduce, scale_factor)
+        what = f"T{int(forest.num_trees)}/D{int(forest.max_depth)}/C{int(forest.num_classes)} forest"
+        try:
+            have = forest.deep_from(scale_factor) if hasattr(forest, "deep_from") else None
+            if have is not None:        # the table carries a choice (tuned earlier, adopted, or set by hand): nothing to do
+                done[s] = {"deep_from": have, "tried": None, "source": "the packed table"}
+                return
+            k = max(1, min(self.AUTO_TUNE_SAMPLE_FRAMES, n, self.AUTO_TUNE_SAMPLE_PIXELS // max(1, h * w)))
+            t0 = time.perf_counter()
+            done[s] = forest.tune(depth_images_in[0:k], labels_reduce, scale_factor)
+            _log.warning("rdf: auto-tuned the deep-level table of a %s on %d of the batch's %dx%d frames in %.0f ms: deep_from=%d "
+                         "(once per packed table; tune() at load time, adopt_packed() or RDF_AUTO_TUNE=0 avoid it)",
+                         what, k, w, h, (time.perf_counter() - t0) * 1e3, done[s]["deep_from"])
+        except Exception as e:      # noqa: BLE001 -- tuning is an optimisation: the evaluation itself must not fail because of it
+            done[s] = {"deep_from": None, "tried": None, "error": f"{type(e).__name__}: {e}"[:300]}
+            _log.warning("rdf: auto-tuning the deep-level table of a %s failed (%s); evaluating from the heap-order records",
+                         what, done[s]["error"])
 
     # -- composite: make_composite_labels_image ------------------------------------------------
     def make_composite_labels_image(self, images, dim_x, dim_y, labels_decision_tree, composite_image):

@@ -21,6 +21,30 @@ from .device import DeviceArray, device_ptr, get_runtime
 from .engine.buffer import GpuBuffer
 
 
+_pending = []       # (graph, lib, capture id, device, last replay's event) of replay objects dropped while a capture was under way
+
+
+def _release_deferred():
+    """Gives the tile-queue slots of dropped replay objects back (rdf_graph_slots_release) once their last replay has finished;
+    does nothing while the current stream is being captured (the entries wait for the next call)."""
+    import torch
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:       # noqa: BLE001 -- (interpreter shutdown)
+        return
+    while _pending:
+        g, lib, cid, dev, event = _pending.pop()
+        try:
+            with torch.cuda.device(dev):         # (the slots are keyed by device: the device of the capture is made current)
+                if event is not None:
+                    event.synchronize()
+                g.reset()
+                lib.rdf_graph_slots_release(cid)
+        except Exception:       # noqa: BLE001 -- a finalizer must not raise
+            pass
+
+
 class HandPipeline:
     def __init__(self, layered_rdf, depth_dims, labels_reduce, eval_to_train_dim_ratio, mean_shift_rounds,
                  mean_shift_variances, fingertip_idxes, intrinsics, plane, depth_mm_level=0, fused_io=True):
@@ -98,9 +122,13 @@ class HandPipeline:
             self._enqueue(depth_image, depth_image_mm_groups, g_id, flip_x)
 
         read_fn = self._read
+        done = torch.cuda.Event()       # re-recorded behind every replay, on the stream the replay was launched on
+        last = [None]
 
         def replay(read=True):
             graph.replay()
+            done.record()
+            last[0] = done
             return read_fn() if read else None
         replay.read = read_fn
         replay.graph = graph
@@ -108,15 +136,17 @@ class HandPipeline:
         # (the graph goes with it), so that captures over a process's lifetime never run out of them
         if named:
             lib, cid, dev = self._lib, int(cap_id.value), torch.cuda.current_device()
+            _release_deferred()      # (whatever an earlier finalizer had to put off)
 
             def _release(g=graph):
                 # the last replay may still be running, on whatever stream it was launched on: its tile-queue slots must
-                # not reach the next capture while its workgroups pull from them (two launches sharing a queue skip tiles);
-                # and the slots are keyed by device, so the device of the capture is made current for the release
-                with torch.cuda.device(dev):
-                    torch.cuda.synchronize(dev)
-                    g.reset()
-                    lib.rdf_graph_slots_release(cid)
+                # not reach the next capture while its workgroups pull from them (two launches sharing a queue skip tiles).
+                # Wait for THAT replay (its event), not for the device: the garbage collector may run this while the other
+                # hand's pipeline is being captured, and a device-wide synchronisation is illegal during a capture (it
+                # would invalidate that capture, and the error would be swallowed here).  While this thread's current
+                # stream is capturing, the release is put off until the next capture() or replay release.
+                _pending.append((g, lib, cid, dev, last[0]))
+                _release_deferred()
             replay.release = weakref.finalize(replay, _release)
         return replay
 

@@ -28,8 +28,11 @@ extern "C" {
 /* 2: rdf_forest_packed_bytes grew (last-level table behind the three per-slot tables: re-pack with this library's
  * rdf_forest_pack); new: rdf_set_last_level_table, rdf_eval_forest_packed_filled.  Nothing was removed or re-typed.
  * 3: rdf_forest_packed_bytes grew again (deep blocks behind the last-level table; `packed` must be 128-byte aligned);
- * new: rdf_set_deep_from, rdf_forest_set_deep_from, rdf_forest_tune, rdf_eval_forest_packed_stats.  Nothing was removed or re-typed. */
-#define RDF_ABI_VERSION 3
+ * new: rdf_set_deep_from, rdf_forest_set_deep_from, rdf_forest_tune, rdf_eval_forest_packed_stats.  Nothing was removed or re-typed.
+ * 4: the choice of rdf_forest_set_deep_from / rdf_forest_tune is kept IN the packed table (its info block) and a table nobody
+ * chose for is walked from the heap-order records (version 3 chose by forest size); new: rdf_forest_info,
+ * rdf_forest_forget, rdf_build_id, RDF_ERR_CAPTURE (was RDF_ERR_BAD_ARG).  Nothing was removed or re-typed; table sizes unchanged. */
+#define RDF_ABI_VERSION 4
 
 #define RDF_OK 0
 #define RDF_ERR_BAD_ARG (-1)     /* negative size, labels_reduce < 1, max_depth outside [0,30] ... */
@@ -38,6 +41,9 @@ extern "C" {
 #define RDF_ERR_NO_DEVICE (-4)   /* no HIP device / not a gfx950 code object */
 #define RDF_ERR_BUILD (-5)       /* the library was built in a way its own kernels do not allow (a forest kernel got static LDS:
                                     its depth tile must sit at LDS address 0) */
+#define RDF_ERR_CAPTURE (-6)     /* `stream` is being captured into a hipGraph and the call needs a synchronous step: the FIRST
+                                    evaluation of a packed table this process has not seen at this address reads the table's info
+                                    block back (evaluate once, or rdf_forest_pack, before capturing) */
 
 /*
  * Forest evaluation.  Replaces `evaluate_image_using_forest`
@@ -164,16 +170,30 @@ int rdf_eval_forest_packed_stats(const uint16_t *depth, int n_img, int dim_x, in
 /*
  * Which table serves a packed forest's deep levels is a property of the forest AND of the frames: a forest whose deep levels
  * are occupied (a trained forest) walks them fastest from the deep blocks, one that sends most pixels down a few paths from
- * the heap-order records, and nothing in the records tells the two apart.  rdf_forest_set_deep_from remembers a choice for
- * one packed table on the current device (level > 0: deep blocks from that level on, 0: never, -1: forget -- the library's
- * default by forest size); rdf_forest_pack into the same memory forgets it.  rdf_forest_tune makes the choice by
+ * the heap-order records, and nothing in the records tells the two apart.  A table nobody chose for is walked from the
+ * heap-order records.  rdf_forest_set_deep_from makes the choice for one packed table (level > 0: deep blocks from that level
+ * on, 0: never, -1: no choice) and WRITES IT INTO THE TABLE's info block (a synchronous 4-byte copy), so it stays with the
+ * table: later evaluations, a copy of the table, another process that maps it all find it (the host keeps what it knows of a
+ * table per device and address and reads the info block once); rdf_forest_pack into the same memory starts over.
+ * rdf_forest_info reports what a table's info block says -- the choice (-1: none made), how many nodes need the exact
+ * numerators (> 0: evaluations need the caller's forest), the scale it was packed for -- reading the block back first if this
+ * process has not seen the table at this address yet (synchronous then; RDF_ERR_BAD_ARG for memory that is not a table of
+ * this shape written by this library version's rdf_forest_pack; all three outputs nullable).
+ * rdf_forest_tune makes the choice by
  * measurement: it evaluates the caller's sample frames (device memory; results go to `labels_scratch`, uint16
  * [n_img][dim_y/r][dim_x/r]) with every candidate -- never, and each block root level -- four to thirteen launches each, keeps the
  * fastest (the deep blocks must beat the heap-order records by 2 %: a tie goes to the default) and reports what it tried
- * (up to 12 entries in levels_tried / ms_tried, all three outputs nullable).  Synchronous.
+ * (up to 12 entries in levels_tried / ms_tried, all three outputs nullable).  Synchronous; tune once per table, at load time.
  * Labels do not depend on the choice.  The process-wide knob rdf_set_deep_from (>= 0) overrides both.
+ * rdf_forest_forget drops what the host remembers about the table at `packed` (scale, exact-node count, choice): call it
+ * before freeing a packed table, or after writing a DIFFERENT packed table to an address this process has evaluated from by
+ * any means other than rdf_forest_pack (device-to-device copy, IPC mapping) -- the next evaluation then reads the info block
+ * again.  Without it such a table would be evaluated with the old table's scale.
  */
 int rdf_forest_set_deep_from(const void *packed, int level);
+int rdf_forest_info(const void *packed, int n_trees, int max_depth, int n_classes, void *stream, int *deep_from,
+                    int *exact_nodes, float *scale);
+int rdf_forest_forget(const void *packed);
 int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed, const float *forest,
                     int n_trees, int max_depth, int n_classes, uint16_t *labels_scratch, int labels_reduce, void *stream,
                     int *chosen_level, int *n_tried, int *levels_tried, float *ms_tried);
@@ -425,6 +445,11 @@ int rdf_event_destroy(void *event);
 int rdf_stream_synchronize(void *stream);
 
 int rdf_abi_version(void);
+/* Identity of the build: 16 hex digits of a SHA-256 over the library's sources (the four .hip files, rdf_device.hpp, this
+ * header) and its compiler flags, baked in at compile time (3d-beats_amd/_build.py).  The Python binding recomputes it from
+ * the sources next to the library and refuses a library built from other sources (an ABI number cannot tell yesterday's
+ * kernels from today's).  "unknown" for a build that did not define it. */
+const char *rdf_build_id(void);
 const char *rdf_error_string(int code);
 
 #ifdef __cplusplus

@@ -52,6 +52,12 @@ def test_binding_table_matches_header(rdf):
     assert lib.rdf_forest_packed_bytes(3, 10, 5) == up128((3 << 10) * (16 + 64)) + deep(3, 10, 1) * 128 + 128
     assert lib.rdf_forest_packed_bytes(3, 10, 9) == up128((3 << 10) * (16 + 96)) + 128
     assert lib.rdf_forest_packed_bytes(0, 10, 4) == 0 and lib.rdf_forest_packed_bytes(4, 0, 4) == 0
+    # deep blocks only while a lane's 32-bit offset reaches every line: (lines + 2^R0) x 128 < 2^32 -- T6/D24 yes, T7 / T8 at D24 no
+    lib.rdf_forest_packed_bytes.restype, lib.rdf_forest_packed_bytes.argtypes = ctypes.c_size_t, [ctypes.c_int] * 3
+    assert lib.rdf_forest_packed_bytes(6, 24, 4) == up128((6 << 24) * (16 + 32) + (6 << 23) * 64 + 64) + deep(6, 24, 2) * 128 + 128
+    for T in (7, 8):
+        assert lib.rdf_forest_packed_bytes(T, 24, 4) == up128((T << 24) * (16 + 32) + (T << 23) * 64 + 64) + 128
+    assert lib.rdf_forest_packed_bytes(8, 22, 4) == up128((8 << 22) * (16 + 32) + (8 << 21) * 64 + 64) + deep(8, 22, 2) * 128 + 128
     assert b"2^31" in lib.rdf_error_string(-3)
 
 
@@ -140,3 +146,37 @@ def test_plain_c_consumer_of_the_shared_library(rdf, gpu_runtime, tmp_path):
                            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "PASS" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_a_library_built_from_other_sources_is_refused(rdf, tmp_path, monkeypatch):
+    """Build identity: librdf_hip.so carries a hash of the sources it was built from (rdf_build_id); the binding recomputes it
+    from csrc/ + include/ and refuses a mismatch -- a library with today's ABI number and yesterday's kernels passes every
+    other check (the .so is git-ignored and travels to the GPU box with the snapshot; file times mean nothing there)."""
+    import shutil
+    from importlib import import_module
+    build = import_module("3d-beats_amd._build")
+    _lib = import_module("3d-beats_amd._lib")
+    so = build.build()
+    assert build.built_id() == build.source_id() and not build.is_stale()
+    lib = ctypes.CDLL(so)
+    lib.rdf_build_id.restype = ctypes.c_char_p
+    assert _lib.check_build_id(lib, so) == build.source_id()
+    # the same library with another id baked in (as if built before the last edit of a kernel)
+    blob = bytearray(open(so, "rb").read())
+    at = blob.find(build.BUILD_ID_MARKER) + len(build.BUILD_ID_MARKER)
+    assert at >= len(build.BUILD_ID_MARKER) and blob.count(build.BUILD_ID_MARKER) == 1
+    blob[at:at + 16] = b"0123456789abcdef"
+    stale = tmp_path / "librdf_hip_stale.so"
+    stale.write_bytes(bytes(blob))
+    assert build.built_id(str(stale)) == "0123456789abcdef"
+    old = ctypes.CDLL(str(stale))
+    old.rdf_build_id.restype = ctypes.c_char_p
+    with pytest.raises(_lib.RdfError, match="built from other sources"):
+        _lib.check_build_id(old, str(stale))
+    monkeypatch.setenv("RDF_ALLOW_STALE_LIBRARY", "1")
+    with pytest.warns(UserWarning, match="built from other sources"):
+        _lib.check_build_id(old, str(stale))
+    monkeypatch.delenv("RDF_ALLOW_STALE_LIBRARY")
+    # is_stale() sees an edited source without looking at file times
+    monkeypatch.setattr(build, "HIPCC_FLAGS", build.HIPCC_FLAGS + ["-DSOMETHING_ELSE"])
+    assert build.is_stale()

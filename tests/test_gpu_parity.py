@@ -40,9 +40,16 @@ def evs(rdf, gpu_runtime):
 
 
 def test_native_library_is_the_one_loaded(rdf, gpu_runtime):
+    """The HIP library is mapped into this process AND was built from the sources next to it: its baked-in build id
+    (rdf_build_id: a hash of the .hip files, the headers and the compiler flags) equals the one recomputed here."""
+    from importlib import import_module
     assert gpu_runtime.name == "hip"
     maps = open("/proc/self/maps").read()
     assert "librdf_hip.so" in maps
+    build = import_module("3d-beats_amd._build")
+    got = gpu_runtime.lib.rdf_build_id()
+    got = got.decode() if isinstance(got, bytes) else got
+    assert len(got) == 16 and got == build.source_id() == build.built_id(), (got, build.source_id(), build.built_id())
 
 
 def test_float_helpers_match_ieee(rdf, gpu_runtime):
@@ -399,8 +406,9 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
             forest = rdf.synth.forest(T, D, C, str(rng.choice(["full", "trained"])), first_tree=it)
             if rng.random() < 0.3:      # a few wild nodes: huge / tiny / non-finite numerators and thresholds
                 k = (forest.shape[1] + 1) // 2
-                forest[:, :k, 0:5] *= rng.choice([1e-30, 1e30, 1e6, np.nan, np.inf], size=(T, k, 5)).astype(np.float32) \
-                    * (rng.random((T, k, 5)) < 0.2) + (rng.random((T, k, 5)) >= 0.2)
+                with np.errstate(invalid="ignore", over="ignore"):      # (inf * 0 and overflow are the point here)
+                    forest[:, :k, 0:5] *= rng.choice([1e-30, 1e30, 1e6, np.nan, np.inf], size=(T, k, 5)).astype(np.float32) \
+                        * (rng.random((T, k, 5)) < 0.2) + (rng.random((T, k, 5)) >= 0.2)
             kinds = [str(k) for k in rng.choice(["dense", "live"], size=n)]
             depth = rdf.synth.frames(kinds, 3000 + it, h, w)
             depth[rng.random(depth.shape) < 0.02] = 0
@@ -1319,9 +1327,23 @@ def test_exact_numerators_come_from_the_callers_forest(rdf, evs, oracle, gpu_run
                 assert rc == 0 and np.array_equal(out.get(), want)
 
 
-def test_first_big_evaluation_tunes_a_big_forest_once(rdf, oracle, gpu_runtime):
-    """DecisionTreeEvaluator picks a big packed forest's deep-level table by measurement at its first batch-sized evaluation
-    (and only then); small forests, small launches and evaluators with auto_tune off are left alone."""
+def _blocks_walked(rdf, gpu_runtime, f, depth, shape):
+    """Deep blocks the launch rdf_eval_forest_packed would make for this batch loads (rdf_eval_forest_packed_stats, counter 7)."""
+    lib = gpu_runtime.lib
+    n, h, w = shape
+    st8 = rdf.DeviceArray((8,), np.uint64).fill(0)
+    tmp = rdf.DeviceArray(shape, np.uint16).fill(65535)
+    rc = lib.rdf_eval_forest_packed_stats(depth.ptr, n, w, h, f.packed(1.0).ptr, f.forest_cu.ptr, int(f.num_trees), int(f.max_depth),
+                                          int(f.num_classes), tmp.ptr, 1, st8.ptr, gpu_runtime.stream())
+    assert rc == 0
+    return int(st8.get()[7])
+
+
+def test_first_big_evaluation_tunes_a_big_forest_once(rdf, oracle, gpu_runtime, caplog, monkeypatch):
+    """DecisionTreeEvaluator's safety net: a big packed forest whose table carries no choice is tuned at its first batch-sized
+    evaluation (and only then), with ONE log line; small forests, small launches, evaluators with auto_tune off and processes
+    with RDF_AUTO_TUNE=0 are left alone; a failing tune does not fail the evaluation."""
+    import logging
     forest_np = rdf.synth.forest(4, 19, 4, "full", 31)              # 32 MB of hot records: the size from which the choice is open
     depth_np = rdf.synth.mixed_batch(10, 5200, 480, 848)
     depth = rdf.to_device(depth_np)
@@ -1329,16 +1351,23 @@ def test_first_big_evaluation_tunes_a_big_forest_once(rdf, oracle, gpu_runtime):
     ev = rdf.DecisionTreeEvaluator()
     out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
     ev.get_labels_forest(f, depth[0:2], out[0:2])                   # two frames: not a batch
-    assert not f.__dict__.get("_tuned")
-    ev.get_labels_forest(f, depth, out)
+    assert not f.__dict__.get("_tuned") and f.deep_from() is None
+    with caplog.at_level(logging.WARNING, logger="rdf_hip"):
+        ev.get_labels_forest(f, depth, out)
+    lines = [r.getMessage() for r in caplog.records if r.name == "rdf_hip"]
+    assert len(lines) == 1 and "auto-tuned" in lines[0] and "T4/D19/C4" in lines[0] and "RDF_AUTO_TUNE=0" in lines[0], lines
     tuned = f.__dict__["_tuned"][1.0]
     assert tuned["deep_from"] in tuned["tried"] and 0 in tuned["tried"] and len(tuned["tried"]) >= 4
+    assert f.deep_from() == tuned["deep_from"]                      # the choice is in the table
     want = np.full((3,) + depth_np.shape[1:], 65535, np.uint16)
     oracle.eval_forest(depth_np[0:3], forest_np, want)
     assert np.array_equal(out[0:3].get(), want)
     before = dict(f.__dict__["_tuned"])
-    ev.get_labels_forest(f, depth, out)
-    assert f.__dict__["_tuned"] == before                           # once
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="rdf_hip"):
+        ev.get_labels_forest(f, depth, out)
+        rdf.DecisionTreeEvaluator().get_labels_forest(f, depth, out)    # (another evaluator: the forest, not the evaluator, remembers)
+    assert f.__dict__["_tuned"] == before and not caplog.records    # once
     small = rdf.DecisionForest.from_numpy(rdf.synth.forest(4, 12, 4, "full", 32))
     ev.get_labels_forest(small, depth, out)
     assert not small.__dict__.get("_tuned")
@@ -1346,7 +1375,207 @@ def test_first_big_evaluation_tunes_a_big_forest_once(rdf, oracle, gpu_runtime):
     ev_off = rdf.DecisionTreeEvaluator()
     ev_off.auto_tune = False
     ev_off.get_labels_forest(f2, depth, out)
-    assert not f2.__dict__.get("_tuned")
+    assert not f2.__dict__.get("_tuned") and f2.deep_from() is None
+    monkeypatch.setenv("RDF_AUTO_TUNE", "0")
+    ev.get_labels_forest(f2, depth, out)
+    assert not f2.__dict__.get("_tuned") and f2.deep_from() is None
+    monkeypatch.delenv("RDF_AUTO_TUNE")
+    # a tune that fails (here: made to raise) is logged and the evaluation goes on from the heap-order records
+    def broken(*a_, **k_):
+        raise MemoryError("no room for the scratch label map")
+    f2.tune = broken
+    out.fill(65535)
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="rdf_hip"):
+        ev.get_labels_forest(f2, depth, out)
+    assert "MemoryError" in f2.__dict__["_tuned"][1.0]["error"] and len(caplog.records) == 1 and "failed" in caplog.records[0].getMessage()
+    assert np.array_equal(out[0:3].get(), want)
+
+
+def test_untuned_table_walks_heap_order_records_and_a_choice_travels_with_the_table(rdf, oracle, gpu_runtime):
+    """Nobody chose: a big forest's batch launch loads no deep block (version 3 of the library switched by size alone).  A
+    choice made for a table is written INTO the table: the table's bytes adopted by another DecisionForest carry it, the
+    adopting side neither packs nor tunes, and the labels are the oracle's."""
+    import logging
+    lib = gpu_runtime.lib
+    forest_np = rdf.synth.forest(4, 19, 4, "full", 57)              # 32 MB of hot records
+    depth_np = rdf.synth.mixed_batch(10, 6400, 480, 848)
+    depth = rdf.to_device(depth_np)
+    want = np.full((2,) + depth_np.shape[1:], 65535, np.uint16)
+    oracle.eval_forest(depth_np[0:2], forest_np, want)
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    assert f.packed(1.0) is not None and f.deep_from() is None
+    assert _blocks_walked(rdf, gpu_runtime, f, depth, depth_np.shape) == 0
+    assert lib.rdf_forest_set_deep_from(f.packed(1.0).ptr, 14) == 0
+    assert f.deep_from() == 14 and _blocks_walked(rdf, gpu_runtime, f, depth, depth_np.shape) > 0
+    table = f.packed_bytes(1.0)
+    # ... the adopting side: same forest, the table as bytes (a file, another process)
+    g = rdf.DecisionForest.from_numpy(forest_np)
+    g.adopt_packed(table, 1.0)
+    ev = rdf.DecisionTreeEvaluator()
+    out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+    ev.get_labels_forest(g, depth, out)                             # batch-sized, auto-tune on: the table's own choice stands
+    assert g.__dict__["_tuned"][1.0] == {"deep_from": 14, "tried": None, "source": "the packed table"}
+    assert g.deep_from() == 14 and _blocks_walked(rdf, gpu_runtime, g, depth, depth_np.shape) > 0
+    assert np.array_equal(out[0:2].get(), want)
+    # "no choice" written through as well
+    assert lib.rdf_forest_set_deep_from(g.packed(1.0).ptr, -1) == 0 and g.deep_from() is None
+    assert _blocks_walked(rdf, gpu_runtime, g, depth, depth_np.shape) == 0
+    assert rdf.DecisionForest.from_numpy(forest_np).adopt_packed(g.packed_bytes(1.0), 1.0) is not None
+    # memory that is not a packed table of this shape is refused at the first look
+    junk = rdf.DecisionForest.from_numpy(forest_np)
+    junk.adopt_packed(np.zeros_like(table), 1.0)
+    with pytest.raises(rdf.RdfError):
+        junk.deep_from()
+    with pytest.raises(rdf.RdfError):
+        ev.get_labels_forest(junk, depth[0:1], out[0:1])
+
+
+def test_a_table_that_lands_on_a_known_address_is_read_afresh(rdf, oracle, gpu_runtime):
+    """The library remembers a table's scale and exact-node count per (device, address).  A DIFFERENT table written to a known
+    address (adopt_packed: upload, no rdf_forest_pack) is evaluated with ITS scale: adopt_packed forgets the address first
+    (rdf_forest_forget) -- without that the old table's scale would be used silently."""
+    lib = gpu_runtime.lib
+    forest_np = rdf.synth.forest(3, 10, 4, "trained", 5)
+    depth_np = rdf.synth.frames(["dense", "live"], 7100, 96, 160)
+    depth = rdf.to_device(depth_np)
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    half = rdf.DecisionForest.from_numpy(forest_np)
+    table_half = half.packed_bytes(0.5)                            # the same forest packed for scale 0.5
+    buf = f.packed(1.0)
+    out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+    rc = lib.rdf_eval_forest_packed(depth.ptr, 2, 160, 96, buf.ptr, f.forest_cu.ptr, 3, 10, 4, None, -1, out.ptr, 1, gpu_runtime.stream())
+    assert rc == 0
+    want1 = np.full(depth_np.shape, 65535, np.uint16)
+    oracle.eval_forest(depth_np, forest_np, want1, 1, None, None, 1.0)
+    assert np.array_equal(out.get(), want1)
+    same_buf = f.adopt_packed(table_half, 1.0)                      # (keyed 1.0 on the Python side: the TABLE says 0.5)
+    assert same_buf.ptr == buf.ptr
+    scale = __import__("ctypes").c_float(0)
+    assert lib.rdf_forest_info(buf.ptr, 3, 10, 4, gpu_runtime.stream(), None, None, __import__("ctypes").byref(scale)) == 0 and scale.value == 0.5
+    # a node with a huge numerator takes the exact path, which multiplies by the table's scale: make one so the scale matters
+    wild = forest_np.copy()
+    wild[0, 0, 0] = 3.0e7
+    fw = rdf.DecisionForest.from_numpy(wild)
+    fw.adopt_packed(rdf.DecisionForest.from_numpy(wild).packed_bytes(0.5), 1.0)
+    out.fill(65535)
+    rc = lib.rdf_eval_forest_packed(depth.ptr, 2, 160, 96, fw.packed(1.0).ptr, fw.forest_cu.ptr, 3, 10, 4, None, -1, out.ptr, 1, gpu_runtime.stream())
+    want_half = np.full(depth_np.shape, 65535, np.uint16)
+    oracle.eval_forest(depth_np, wild, want_half, 1, None, None, 0.5)
+    assert rc == 0 and np.array_equal(out.get(), want_half)
+
+
+def test_first_evaluation_of_an_unseen_table_cannot_be_captured(rdf, gpu_runtime):
+    """RDF_ERR_CAPTURE, not a generic bad argument: the first evaluation of a table the process has not seen reads its info
+    block back, which a stream under capture cannot do; after one evaluation (or a pack) capture works."""
+    import torch
+    lib = gpu_runtime.lib
+    forest_np = rdf.synth.forest(2, 8, 4, "trained", 3)
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    f.adopt_packed(rdf.DecisionForest.from_numpy(forest_np).packed_bytes(1.0), 1.0)
+    depth = rdf.to_device(rdf.synth.frames(["dense"], 1, 64, 96))
+    out = rdf.DeviceArray((1, 64, 96), np.uint16).fill(65535)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    rcs = []
+    with torch.cuda.graph(graph, stream=side):
+        rcs.append(lib.rdf_eval_forest_packed(depth.ptr, 1, 96, 64, f.packed(1.0).ptr, f.forest_cu.ptr, 2, 8, 4, None, -1, out.ptr, 1,
+                                              gpu_runtime.stream()))
+        out.fill(65535)         # (something to record: an empty capture is an error of its own on some runtimes)
+    assert rcs == [-6] and b"captured" in lib.rdf_error_string(-6)
+    assert lib.rdf_eval_forest_packed(depth.ptr, 1, 96, 64, f.packed(1.0).ptr, f.forest_cu.ptr, 2, 8, 4, None, -1, out.ptr, 1,
+                                      gpu_runtime.stream()) == 0
+
+
+def test_deep_blocks_at_config5_size(rdf, evs, oracle, gpu_runtime):
+    """BASELINE config 5's forest shape on a forest whose deep levels are occupied: T8/D22/C4 balanced (3.6 GiB of packed
+    tables, 1.2 GB of them deep blocks: block offsets up to 2^29 inside a root level), two dense 1280x720 frames, the walk
+    taking over at root level 11 (what DecisionForest.tune picks on config 5's shard) and at 20 (the last block alone), and the
+    heap-order records: the oracle's labels every time.  (tree_eval.cu:95-128 is what all three compute.)"""
+    lib = gpu_runtime.lib
+    synth = rdf.synth
+    forest = synth.forest(8, 22, 4, "balanced", calib=synth.frames(["dense"] * 4, 9000, 720, 1280))
+    depth = synth.frames(["dense", "dense"], 5000, 720, 1280)
+    want = np.full(depth.shape, 65535, np.uint16)
+    st = np.zeros(3, np.uint64)
+    oracle.eval_forest(depth, forest, want, stats=st)
+    px = int(st[0])
+    assert px == depth.size and int(st[1]) == px * 8 * 22 and int(st[2]) == px * 8      # every walk reaches level D-1
+    f = rdf.DecisionForest.from_numpy(forest)
+    d = rdf.to_device(depth)
+    try:
+        for level in (11, 20, 0):
+            lib.rdf_set_deep_from(level)
+            out = rdf.DeviceArray(depth.shape, np.uint16).fill(65535)
+            evs["packed"].get_labels_forest(f, d, out)
+            got = out.get()
+            assert np.array_equal(got, want), (level, int((got != want).sum()))
+            blocks = _blocks_walked(rdf, gpu_runtime, f, d, depth.shape)
+            assert blocks == (px * 8 * (len(range(level, 20, 3)) + 1) if level else 0), (level, blocks)
+    finally:
+        lib.rdf_set_deep_from(-1)
+
+
+def _spine_forest(T, D, C, spine_trees):
+    """A forest of 2^D - 1 nodes per tree that costs no host memory to speak of: all zeros (numpy's zeros are untouched
+    pages) except the leftmost node of every level in `spine_trees`.  Such a node compares depth[x] - 65535 (the v probe lies
+    262 columns to the right: outside a 160-column frame) with a threshold that falls from level to level, so the lanes of a
+    wave leave the walk a few per level (to the right: a leaf with a one-hot PDF) and the rest goes on to the left, down to
+    level D - 1.  All-zero trees end at their root (tree_eval.cu:107-121: 0 < 0 is false, the right side is a leaf of zeros)."""
+    f = np.zeros((T, (1 << D) - 1, 7 + 2 * C), np.float32)
+    rows = {}
+    for k in spine_trees:
+        for j in range(D):
+            row = np.zeros(7 + 2 * C, np.float32)
+            row[2] = float(1 << 20)                                   # v.x: an integer-record numerator (|a| < 2^21)
+            row[4] = float((4400 - 30 * j - 7 * k) - 65535)           # left iff depth < 4400 - 30 j - 7 k
+            row[5] = -1.0 if j < D - 1 else 0.0                       # left: continue (a leaf on the last level)
+            row[6] = 0.0                                              # right: leaf
+            row[7 + (j + k) % C] = (1 + (j % 3)) / 4.0                # left PDF (used on the last level only)
+            row[7 + C + (j + 2 * k + 1) % C] = (2 + (j % 5)) / 8.0    # right PDF
+            f[k, (1 << j) - 1] = row
+            rows[(k, (1 << j) - 1)] = row
+    return f, rows
+
+
+@pytest.mark.parametrize("T,deep", [(6, True), (8, False)])
+def test_depth_24_forests_and_the_32_bit_block_offsets(rdf, oracle, gpu_runtime, T, deep):
+    """The deep walk addresses a block as 64-bit base + 32-bit offset; a finished lane's offset points at the zero line behind
+    the LAST block, which only fits while the whole table stays under 4 GiB.  T6/D24/C4 (3.7 GB of blocks, offsets up to
+    2^32 - 2^26) walks the blocks with finished and walking lanes side by side in every wave; T8/D24/C4 (4.9 GB) gets no deep
+    blocks at all (round 4 let the offset wrap there) and is walked from the heap-order records.  Labels are the oracle's."""
+    lib = gpu_runtime.lib
+    D, C = 24, 4
+    with_deep = lib.rdf_forest_packed_bytes(T, D, C)
+    slots_and_last = ((T << D) * (16 + 32) + (T << (D - 1)) * 64 + 64 + 127) & ~127
+    assert (with_deep > slots_and_last + 128) == deep
+    forest_np, rows = _spine_forest(T, D, C, spine_trees=(0, 2, T - 1))
+    depth_np = rdf.synth.frames(["dense", "dense", "live"], 4300, 96, 160)
+    want = np.full(depth_np.shape, 65535, np.uint16)
+    st = np.zeros(3, np.uint64)
+    oracle.eval_forest(depth_np, forest_np, want, stats=st)
+    assert int(st[1]) > 6 * int(st[0]) and len(np.unique(want)) >= 4          # walks of many lengths, several classes
+    f = rdf.DecisionForest(T, D, C)                                  # zeros on the device; the spine nodes one by one
+    for (k, node), row in rows.items():
+        f.forest_cu[k][node].set(row)
+    depth = rdf.to_device(depth_np)
+    ev = rdf.DecisionTreeEvaluator()
+    ev.auto_tune = False
+    try:
+        for level in (19, 22, 10, 0):
+            lib.rdf_set_deep_from(level)
+            for block in (256, 512):
+                lib.rdf_set_block_threads(block)
+                out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+                ev.get_labels_forest(f, depth, out)
+                got = out.get()
+                assert np.array_equal(got, want), (T, level, block, int((got != want).sum()))
+            lib.rdf_set_block_threads(0)
+            blocks = _blocks_walked(rdf, gpu_runtime, f, depth, depth_np.shape)
+            assert (blocks > 0) == (deep and level > 0), (T, level, blocks)
+    finally:
+        lib.rdf_set_deep_from(-1)
+        lib.rdf_set_block_threads(0)
 
 
 def test_deep_blocks_fuzz(rdf, evs, oracle, gpu_runtime):

@@ -7,6 +7,9 @@ walks; pass 2 runs every wave's level loop only for the MEAN of them, which is w
 pixel the moment its four walks have ended, at no cost and from an unbounded supply (labels are wrong in pass 2: walks are cut
 short).  The ratio of the two timings is the zero-overhead bound of lane refill, measured on the kernel itself.
 
+The experiment's code is not in the product source: it is kept as profiles/r04_refill_bound.patch (round 5 moved it out).
+
+    patch -p1 < profiles/r04_refill_bound.patch        (on a scratch copy of the tree)
     hipcc ... -DRDF_EXPERIMENT_REFILL_BOUND -o tools/bin/librdf_refill_bound.so <the four .hip files>
     python3 tools/refill_bound_gpu.py [--topology trained] [--frames 128]
 """
