@@ -1206,6 +1206,7 @@ def main():
             ft_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_trained", lambda: synth.forest(T, D, C, "trained")))
             ft = rdf.DecisionForest.from_numpy(ft_np)
             ft.packed(1.0)
+            tune_t = tune_forest(ft, depth[0:min(32, F)])
             res = leg_cfg2(200, ft)
             lab_t = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
             for _ in range(2):
@@ -1223,7 +1224,7 @@ def main():
             rdf_oracle.eval_forest(frames_np[0:ns], ft_np, want, n_threads=min(host_cores(), rdf_oracle.max_threads()), stats=st)
             mism = int((want != lab_t[0:ns].get()).sum())
             assert mism == 0, f"trained-like topology: GPU labels differ from the oracle in {mism} pixels"
-            res.update({"topology": "trained", "batch": {"value": round(F * H * W / ms_t / 1e3, 2), "unit": "Mpix/s",
+            res.update({"topology": "trained", "tune": tune_t, "batch": {"value": round(F * H * W / ms_t / 1e3, 2), "unit": "Mpix/s",
                                                           "ms_per_step": round(ms_t, 4), "frames": F, "steps": 10},
                         "mean_levels_per_pixel_and_tree": round(float(st[1]) / max(1.0, float(st[0]) * T), 2),
                         "parity": {"frames_checked": ns, "differing_pixels": mism, "checker": "oracle/rdf_oracle.c on the host"}})
