@@ -52,13 +52,6 @@
 #include "../../include/rdf_hip.h"
 #include "rdf_device.hpp"
 
-// Trees that walk their deep blocks side by side (k_eval_forest<..., DEEP>).  One: the walk is bound by the L1's line
-// accesses (seven per block and lane), not by the lines in flight -- two trees side by side need 56 registers of block
-// and ran 9.5 against 7.8 ms (spills), 8.4 ms when bounded to four waves per SIMD (profiles/r04_deep_variants.txt).
-#ifndef RDF_DEEP_W
-#define RDF_DEEP_W 1
-#endif
-
 namespace {
 
 constexpr int kGroup = 4;          // trees walked interleaved by one lane (template GROUP: 1 and 2 for smaller forests)
@@ -155,11 +148,12 @@ static_assert(sizeof(NodeRec16) == 16 && sizeof(PackInfo) == 128 && sizeof(LastL
 //     forests of five to eight classes: root on level D - 1: {node, pad, left PDF (32 B), right PDF (32 B)}.
 // Block roots sit on levels R0 = D - 2 (or D - 1), R0 - 3, R0 - 6, ... >= 0; the blocks of one root level are contiguous,
 // [tree][root's index on its level], smaller root levels first; one all-zero line and a 64-byte trailer follow.
-// The kernel (k_eval_forest<..., DEEP>) walks the levels below `deep_from` (a root level, chosen per launch) from this
-// table, ONE TREE AFTER THE OTHER: a lane loads a whole block with seven back-to-back 16-byte loads (one line fill; the
-// L1 does not keep a line from one level to the next, measured in round 2), walks its three levels out of registers
-// (the record of the second and third level is picked by the sides taken: 16 v_cndmask per block) and moves on to the
-// next block -- a third of the lines from beyond L2 per walk, and the leaf comes with the last of them.
+// The kernel (k_eval_forest<..., DEEP>) walks the levels below `deep_from` (a root level, chosen per table) from this
+// table, ONE TREE AFTER THE OTHER, and the WAVE fetches its lanes' blocks together: eight LDS-DMA loads of eight whole lines
+// each into an 8-KB slab per wave, from which every lane reads the three records its walk takes (see "deep blocks" in the
+// kernel; round 4's walk had every lane fetch its own block with seven 16-byte loads -- seven L1 look-ups per line -- and
+// was bound by the L1's line accesses: 7.9 against 6.7 ms on the bench batch, 23.4 against 18.4 ms on config 5's shard,
+// profiles/r05_deep_coop.txt) -- a third of the lines from beyond L2 per walk, and the leaf comes with the last of them.
 // Usable from root level R on iff no node of a level >= R is flagged kFlagExact and (for the last block) every node
 // of level D - 1 has two leaves: k_pack leaves both facts in the trailer {1 + deepest level with an exact node,
 // nodes of level D - 1 that are not plain two-leaf nodes}.
@@ -174,18 +168,11 @@ __host__ __device__ inline size_t deep_total_lines(int n_trees, int max_depth, i
     const int R0 = max_depth - deep_last_levels(cpad);
     return deep_lines_before(n_trees, R0, R0 % 3) + ((size_t)n_trees << R0);
 }
-// A lane addresses its block as {wave-uniform 64-bit base of its tree's blocks of the root level} + {32-bit byte offset}: a
-// walking lane's offset is its heap index x 128 (root levels up to 23), a lane whose walk has ended points at the table's
-// all-zero line BEHIND the last block with the offset (zero line - base), and the base of tree 0 lies up to 2^R lines in front
-// of the level's first block (the 2^R of a heap index folded in).  So a forest gets deep blocks only while
-// (all lines + 2^R0) x 128 stays below 2^32: T4/D24 (2.5 GB of blocks) and T6/D24 (3.7 GB) do, T8/D24 (4.9 GB) does not and is
-// walked from the heap-order records -- round 4 let the offset wrap there (labels stayed right, finished lanes fetched live
-// blocks and probed far from their pixel).
+// A lane's block is addressed as {wave-uniform 64-bit base of its tree's blocks of the root level} + {32-bit byte offset =
+// heap index x 128}: root levels up to 23, i.e. forests of up to 24 levels.
 __host__ __device__ inline bool deep_possible(int n_trees, int max_depth, int cpad)
 {
-    if (!(n_trees >= 1 && (cpad == 4 || cpad == 8) && max_depth >= 5 && max_depth <= 24)) return false;
-    const int R0 = max_depth - deep_last_levels(cpad);
-    return ((deep_total_lines(n_trees, max_depth, cpad) + ((size_t)1 << R0)) << 7) < ((size_t)1 << 32);
+    return n_trees >= 1 && (cpad == 4 || cpad == 8) && max_depth >= 5 && max_depth <= 24;
 }
 
 struct EvalArgs {
@@ -215,6 +202,7 @@ struct EvalArgs {
     uint32_t lds_nodes_off; // byte offsets inside the dynamic LDS allocation (the depth tile is at 0)
     uint32_t lds_mail_off;
     uint32_t lds_list_off;
+    uint32_t lds_slab_off; // (DEEP) the waves' block slabs: 8 KB each, 1-KB aligned
     const float *packed_pdf;   // leaf PDFs [T][2^D][2][cpad], 16-byte aligned rows (packed path), or null
     const uint4 *last_level;   // LastLevelRec [T][2^(D-1)] followed by the trailer (see k_pack), or null
     uint32_t last_level_min;   // deepest-level nodes in use from which the table is taken
@@ -372,7 +360,8 @@ struct EvalArgsN {
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT, int NL = 1, bool TW = false, bool DEEP = false>
 // second launch bound = waves per SIMD the register allocation must allow: three 512-thread workgroups per CU are six
 // waves per SIMD (80 VGPRs; the 4-wide walk needs 86 without the bound and spills two dwords with it)
-__global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgsN<NL> ka)
+// (DEEP: the block slabs leave room for two 512-thread or four 256-thread workgroups per CU = four waves per SIMD)
+__global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4) void k_eval_forest(const EvalArgsN<NL> ka)
 {
     const uint32_t role = NL > 1 ? blockIdx.x % NL : 0u;           // workgroup-uniform
     const uint32_t block_id = NL > 1 ? blockIdx.x / NL : blockIdx.x, n_blocks = NL > 1 ? gridDim.x / NL : gridDim.x;
@@ -695,25 +684,37 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
         for (uint32_t first = TW ? (tw_row < tile_rows ? tw_row * 64u : n_valid) : wave * 64u; first < n_valid; first += BLOCK) {
             const uint32_t slot = first + (uint32_t)lane;
             uint32_t entry = slot;
+            // DEEP: the wave fetches its deep blocks TOGETHER (every lane loads slots of other lanes' blocks), so a lane without a
+            // pixel to evaluate cannot leave the loop body: it stays as a lane whose tree slots are all idle (`live` false) and
+            // skips only the stores
+            bool live = true;
             if (compact) {
-                if (slot >= n_valid) continue;
-                entry = px_list[slot];
+                if (slot >= n_valid) {
+                    if (!DEEP) continue;
+                    live = false;
+                }
+                entry = px_list[live ? slot : first];
             }
             const int ly = (int)(ty * tile_rows + (entry >> 6));
             const int px = (int)(tx * 64u + (entry & 63u));
-            if (!compact && (ly >= a.Hl || px >= a.Wl)) continue;
+            if (!compact && (ly >= a.Hl || px >= a.Wl)) {
+                if (!DEEP) continue;
+                live = false;
+            }
             const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)px;
             const int x = px * a.r, y = ly * a.r;
             const int xl = x - tx0, yl = y - ty0;   // this pixel, relative to the staged tile
             // tree_eval.cu:81-89 (a listed pixel passed these already)
             bool skip = false;
-            if (!compact && a.filter_class != -1) skip = (int)a.filter[i] != a.filter_class;
+            if (!compact && live && a.filter_class != -1) skip = (int)a.filter[i] != a.filter_class;
             uint32_t d = 0u;
-            if (!skip) d = (uint32_t)tprobe_value(tprobe_issue(pc, (uint32_t)xl * 2u, (uint32_t)yl));
-            if (!compact && (skip || d == 0u || d == kNoPixel)) {
+            if (!skip && live) d = (uint32_t)tprobe_value(tprobe_issue(pc, (uint32_t)xl * 2u, (uint32_t)yl));
+            if (!compact && live && (skip || d == 0u || d == kNoPixel)) {
                 if (a.fill_untouched && (!TW || tw_tree == 0u)) a.labels[i] = (uint16_t)kNoPixel;
-                continue;
+                if (!DEEP) continue;
+                live = false;
             }
+            if (DEEP && !live) d = 1u;      // (finite arithmetic for a lane that only helps to fetch)
             const float df = (float)d;
             // refined reciprocal shared by every divide of this pixel (fast path only), in round-to-nearest
             const float r0 = __builtin_amdgcn_rcpf(df);
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                     // beyond T.  "Still walking" is simply (int)h > 0.
                     uint32_t h[GROUP];
 #pragma unroll
-                    for (int k = 0; k < GROUP; ++k) h[k] = (kb + k) < a.T ? 1u : kIdle;
+                    for (int k = 0; k < GROUP; ++k) h[k] = (live && (kb + k) < a.T) ? 1u : kIdle;
 
                     // The level loop runs in round-down mode (NodeRec16).  The sums of the previous group's leaf PDFs
                     // are pinned in front of the switch; the reference-layout kernel switches back for good at its
@@ -877,188 +878,129 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             h[k] = walking ? next : h[k];
                         }
                     }
-                    // ---- deep blocks: the levels from a.deep_from on, one tree after the other.  A lane loads the seven records of
-                    // its block -- one 128-byte line -- at once: one fill, and the L1 and L2 do not keep a line from one level
-                    // to the next (a record fetched later from the same line was a second fetch from beyond L2 every time:
-                    // profiles/r04_deep_variants.txt); it walks the block's levels out of registers -- the record of the
-                    // second and third level is picked by the sides taken -- and moves on to the next block.  The last block
-                    // brings the leaf PDFs of level D-1 along.  The PDFs are added tree after tree (the canonical order), in
-                    // round-to-nearest: the mode goes back and forth per tree.  A lane whose walk has ended reads the table's
-                    // all-zero line (offsets 0: its discarded probes are the pixel itself); one that ended above level D-1
-                    // takes its leaf from the PDF table. ----
-                    if (DEEP && deep_on) {
+                    if constexpr (DEEP) {
+                      if (deep_on) {
+                        // ---- deep blocks: the levels from a.deep_from on, one tree after the other, three levels per block (the last
+                        // block: two levels and their four leaf PDFs; five to eight classes: one level and its two PDFs).  A block is
+                        // one 128-byte line, and the WAVE fetches the 64 blocks its lanes stand on with eight LDS-DMA loads of 1 KB: in
+                        // load k the eight lanes 8 i .. 8 i + 7 fetch the eight 16-byte slots of the block lane 8 k + i stands on (its
+                        // offset comes over by ds_bpermute; a lane whose walk has ended names the level's first block) --
+                        // eight whole lines per instruction, 64 line look-ups per block step where a lane fetching its own block with
+                        // seven 16-byte loads made 448 (round 4: TA busy 94-97 %) -- straight into the wave's 8-KB slab
+                        // [lane's block][slot]; then each lane reads the three records its walk takes (root, the child and the
+                        // grandchild it goes to) with three ds_read_b128.  The slot a record sits in is XOR-ed with bits 1-3 of the
+                        // owning lane, so that the 16 lanes of a ds_read_b128 group hit 16 different bank quads when they read the same
+                        // record (an LDS-DMA's destination is lane-linear: the swizzle is applied to the SOURCE address).  Every lane of
+                        // the wave takes part in the fetch, which is why lanes without a pixel stay in the loop (`live`).  The PDFs are
+                        // added tree after tree (the canonical order) in round-to-nearest: the mode goes back and forth per tree.  A
+                        // lane whose walk has ended decodes an all-zero record (offsets 0: its discarded probes are the pixel itself);
+                        // one that ended above level D-1 takes its leaf from the PDF table. ----
                         const int R0 = a.D - kDeepLast, Lmin = R0 % 3;
-                        const size_t zero_at = deep_total_lines(a.T, a.D, a.cpad) << 7;
                         const f2 r2 = {rcp_s, rcp_s};
                         const f2 m2 = {kMagic, kMagic};
-                        constexpr int W = GROUP >= RDF_DEEP_W ? RDF_DEEP_W : 1;     // trees side by side
+                        unsigned char *slab = lds_raw + a.lds_slab_off + wave * 8192u;
+                        const unsigned char *my_block = slab + ((uint32_t)lane << 7);
+                        const uint32_t my_swz = ((uint32_t)lane >> 1) & 7u;
+                        // the record the lane fetches in an even load (owner 8 k + lane / 8, swizzle (4 k + lane / 16) & 7): slot ^ swizzle
+                        const uint32_t src_rec = (((uint32_t)lane & 7u) ^ ((uint32_t)lane >> 4)) << 4;
 #pragma unroll
-                        for (int k0 = 0; k0 < GROUP; k0 += W) {
-                            uint32_t hk[W];
+                        for (int k0 = 0; k0 < GROUP; ++k0) {
+                            uint32_t hk = h[k0];
+                            const int tk = min(kb + k0, a.T - 1);
+                            auto fetch_blocks = [&](int R) {
+                                const size_t base_at = (deep_lines_before(a.T, R, Lmin) + ((size_t)tk << R) - ((size_t)1 << R)) << 7;
+                                // (a lane whose walk has ended names the level's first block of the tree: one line the whole chip shares,
+                                // so every lane issues all eight loads and no load sits behind a branch -- fetching nothing for such
+                                // lanes, 8 x s_cbranch_execz, cost 3 % on a forest where every lane walks and gained nothing on one where
+                                // half of them have ended; what such a lane reads from its slab is replaced by an all-zero record)
+                                const uint32_t off = ((int)hk > 0 ? hk : (1u << R)) << 7;
+                                const char *tb = reinterpret_cast<const char *>(a.deep) + base_at;
 #pragma unroll
-                            for (int w = 0; w < W; ++w) hk[w] = k0 + w < GROUP ? h[k0 + w] : kIdle;
-                            // one level of the W trees: decode, every probe issued, then the decisions
-                            auto level = [&](const uint4 (&rec)[W]) {
-                                Node n[W];
-                                TileProbe qu[W], qv[W];
-#pragma unroll
-                                for (int w = 0; w < W; ++w) {
-                                    n[w] = decode_node(rec[w]);
-                                    const f2 nu = {n[w].ax, n[w].ay};
-                                    const f2 nv = {n[w].bx, n[w].by};
-                                    const f2 tu = __builtin_elementwise_fma(nu, r2, m2);
-                                    const f2 tv = __builtin_elementwise_fma(nv, r2, m2);
-                                    qu[w] = tprobe_issue(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky);
-                                    qv[w] = tprobe_issue(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky);
-                                    if (STATS && c0 == 0) {
-                                        st_lv += (int)hk[w] > 0 ? 1u : 0u;
-                                        st_far += far_lines(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky, (int)hk[w] > 0, img_boff);
-                                        st_far += far_lines(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky, (int)hk[w] > 0, img_boff);
-                                    }
+                                for (int k = 0; k < 8; ++k) {
+                                    const uint32_t owner_off = (uint32_t)__shfl((int)off, k * 8 + (lane >> 3));
+                                    const uint32_t byte = owner_off + (src_rec ^ ((k & 1) ? 64u : 0u));
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb + byte),
+                                                                     (__attribute__((address_space(3))) void *)(slab + k * 1024), 16, 0, 0);
                                 }
-#pragma unroll
-                                for (int w = 0; w < W; ++w) {
-                                    const int g = tprobe_value(qu[w]) - tprobe_value(qv[w]) - (int)n[w].lo16;
-                                    const uint32_t next = walk_step(hk[w], g, n[w].w2, n[w].flags);
-                                    hk[w] = (int)hk[w] > 0 ? next : hk[w];
+                                if (STATS && c0 == 0) st_blk += (int)hk > 0 ? 1u : 0u;
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            };
+                            auto slot_of = [&](bool mine, uint32_t rec) -> uint4 {       // a record of this lane's block, if it has one
+                                const uint4 v = *reinterpret_cast<const uint4 *>(my_block + ((rec ^ my_swz) << 4));
+                                return select4(mine, v, make_uint4(0u, 0u, 0u, 0u));
+                            };
+                            auto slot = [&](uint32_t rec) -> uint4 { return slot_of((int)hk > 0, rec); };
+                            auto level1 = [&](const uint4 rec) {
+                                const Node n = decode_node(rec);
+                                const f2 nu = {n.ax, n.ay};
+                                const f2 nv = {n.bx, n.by};
+                                const f2 tu = __builtin_elementwise_fma(nu, r2, m2);
+                                const f2 tv = __builtin_elementwise_fma(nv, r2, m2);
+                                const TileProbe qu = tprobe_issue(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky);
+                                const TileProbe qv = tprobe_issue(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky);
+                                if (STATS && c0 == 0) {
+                                    st_lv += (int)hk > 0 ? 1u : 0u;
+                                    st_far += far_lines(pc, (__float_as_uint(tu.x) << 1) + kx2, __float_as_uint(tu.y) + ky, (int)hk > 0, img_boff);
+                                    st_far += far_lines(pc, (__float_as_uint(tv.x) << 1) + kx2, __float_as_uint(tv.y) + ky, (int)hk > 0, img_boff);
                                 }
+                                const int g = tprobe_value(qu) - tprobe_value(qv) - (int)n.lo16;
+                                const uint32_t next = walk_step(hk, g, n.w2, n.flags);
+                                hk = (int)hk > 0 ? next : hk;
                             };
-                            // the seven records of the block of root level R a lane's walk stands on: wave-uniform base of the
-                            // tree's blocks of that level (the 2^R of a heap index folded in) + the lane's byte offset; the
-                            // all-zero line for a lane that is not walking
-                            uint4 q[7][W];
-                            auto load_block = [&](int R) {
-#pragma unroll
-                                for (int w = 0; w < W; ++w) {
-                                    const int tk = min(kb + k0 + w, a.T - 1);
-                                    const size_t base_at = (deep_lines_before(a.T, R, Lmin) + ((size_t)tk << R) - ((size_t)1 << R)) << 7;
-                                    // (zero line - base fits 32 bits for every forest deep_possible() admits)
-                                    const uint32_t off = (int)hk[w] > 0 ? hk[w] << 7 : (uint32_t)(zero_at - base_at);
-                                    const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.deep) + base_at + off);
-                                    // (five to eight classes, last block {node, pad, left PDF, right PDF}: records 1 and 6 hold nothing)
-                                    const bool short_block = CMAX == 8 && R == R0;
-#pragma unroll
-                                    for (int i = 0; i < 7; ++i) {
-                                        if (CMAX == 8 && (i == 1 || i == 6) && short_block) q[i][w] = make_uint4(0u, 0u, 0u, 0u);
-                                        else q[i][w] = bp[i];
-                                    }
-                                    if (STATS && c0 == 0) st_blk += (int)hk[w] > 0 ? 1u : 0u;     // (a block is a line of its own)
-                                }
-                                // (issued together -- the line is filled once -- before anything is decoded)
-#pragma unroll
-                                for (int w = 0; w < W; ++w)
-                                    asm volatile("" : "+v"(q[0][w].x), "+v"(q[1][w].x), "+v"(q[2][w].x), "+v"(q[3][w].x), "+v"(q[4][w].x),
-                                                      "+v"(q[5][w].x), "+v"(q[6][w].x));
-                            };
-                            auto any_walking = [&]() {
-                                bool any_w = false;
-#pragma unroll
-                                for (int w = 0; w < W; ++w) any_w |= (int)hk[w] > 0;
-                                return __any(any_w) != 0;
-                            };
-                            // records 3 .. 6 by the sides taken on the block's first two levels: 3 + 2 sa + sb
-                            auto third = [&](const bool (&sa)[W], uint4 (&out)[W]) {
-#pragma unroll
-                                for (int w = 0; w < W; ++w) {
-                                    const bool sb = (hk[w] & 1u) != 0u;
-                                    out[w] = select4(sa[w], select4(sb, q[6][w], q[5][w]), select4(sb, q[4][w], q[3][w]));
-                                }
-                            };
-                            uint4 rec[W];
-                            bool sa[W];
                             for (int R = a.deep_from; R < R0; R += 3) {
-                                if (!any_walking()) break;
-                                load_block(R);
-                                level(q[0]);
-#pragma unroll
-                                for (int w = 0; w < W; ++w) {
-                                    sa[w] = (hk[w] & 1u) != 0u;
-                                    rec[w] = select4(sa[w], q[2][w], q[1][w]);
-                                }
-                                level(rec);
-                                third(sa, rec);
-                                level(rec);
+                                if (!__any((int)hk > 0)) break;
+                                fetch_blocks(R);
+                                level1(slot(0u));
+                                const uint32_t sa = hk & 1u;
+                                level1(slot(1u + sa));
+                                level1(slot(3u + 2u * sa + (hk & 1u)));
                             }
-                            // ---- the last block: the last two levels and their four leaf PDFs (five to eight classes: the last
-                            // level's node, a pad, its two 32-byte PDFs) ----
-                            bool have[W];               // this lane's walk reached level D-1 (every node there has two leaves)
-                            uint4 p0[W], p1[W];         // its leaf PDF (p1: classes 4-7)
-#pragma unroll
-                            for (int w = 0; w < W; ++w) { have[w] = false; p0[w] = p1[w] = make_uint4(0u, 0u, 0u, 0u); }
-                            if (any_walking()) {
-                                load_block(R0);
-                                if (CMAX == 4) {
-                                    level(q[0]);
-#pragma unroll
-                                    for (int w = 0; w < W; ++w) {
-                                        sa[w] = (hk[w] & 1u) != 0u;
-                                        have[w] = (int)hk[w] > 0;
-                                        rec[w] = select4(sa[w], q[2][w], q[1][w]);
-                                    }
-                                    level(rec);
-                                    third(sa, p0);
-                                } else {
-#pragma unroll
-                                    for (int w = 0; w < W; ++w) have[w] = (int)hk[w] > 0;
-                                    level(q[0]);
-#pragma unroll
-                                    for (int w = 0; w < W; ++w) {
-                                        const bool sb = (hk[w] & 1u) != 0u;
-                                        p0[w] = select4(sb, q[4][w], q[2][w]);
-                                        p1[w] = select4(sb, q[5][w], q[3][w]);
-                                    }
+                            bool have = false;                  // this lane's walk reached level D-1 (every node there has two leaves)
+                            uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = make_uint4(0u, 0u, 0u, 0u);
+                            if (__any((int)hk > 0)) {
+                                fetch_blocks(R0);
+                                if (CMAX == 4) {                // {root, left, right, four leaf PDFs}
+                                    level1(slot(0u));
+                                    const uint32_t sa = hk & 1u;
+                                    have = (int)hk > 0;
+                                    level1(slot(1u + sa));
+                                    p0 = slot_of(have, 3u + 2u * sa + (hk & 1u));
+                                } else {                        // {node, pad, left PDF (32 bytes), right PDF (32 bytes)}
+                                    have = (int)hk > 0;
+                                    level1(slot(0u));
+                                    const uint32_t sb = hk & 1u;
+                                    p0 = slot_of(have, 2u + 2u * sb);
+                                    p1 = slot_of(have, 3u + 2u * sb);
                                 }
                             }
-                            // ---- the leaf PDFs of these trees, in tree order (the canonical order), in round-to-nearest; a walk that
-                            // ended above level D-1 takes its leaf from the PDF table ----
-                            bool early[W], any_early = false;
-#pragma unroll
-                            for (int w = 0; w < W; ++w) {
-                                early[w] = (int)hk[w] < 0 && hk[w] != kIdle && !have[w];
-                                any_early |= early[w];
-                            }
-                            if (__any(any_early)) {
-#pragma unroll
-                                for (int w = 0; w < W; ++w) {
-                                    const int tk = min(kb + k0 + w, a.T - 1);
-                                    if (STATS && c0 == 0) st_leaf += lines_of(early[w], (hk[w] & ~kDone) * (uint32_t)(a.cpad * 4));
-                                    // 16-byte rows: (((tree << D) + node) * 2 + side) * (cpad / 4), node * 2 + side = h & ~kDone (add_leaf_pdf)
-                                    const uint4 *row = reinterpret_cast<const uint4 *>(a.packed_pdf) +
-                                                       (early[w] ? (((size_t)tk << (a.D + 1)) + (hk[w] & ~kDone)) * (size_t)(a.cpad >> 2) : (size_t)0);
-                                    const uint4 e0 = row[0];
-                                    p0[w] = select4(early[w], e0, p0[w]);
-                                    if (CMAX == 8) {
-                                        const uint4 e1 = row[1];
-                                        p1[w] = select4(early[w], e1, p1[w]);
-                                    }
+                            const bool early = (int)hk < 0 && hk != kIdle && !have;     // ended above level D-1: the PDF table has its leaf
+                            if (__any(early)) {
+                                if (STATS && c0 == 0) st_leaf += lines_of(early, (hk & ~kDone) * (uint32_t)(a.cpad * 4));
+                                const uint4 *row = reinterpret_cast<const uint4 *>(a.packed_pdf) +
+                                                   (early ? (((size_t)tk << (a.D + 1)) + (hk & ~kDone)) * (size_t)(a.cpad >> 2) : (size_t)0);
+                                const uint4 e0 = row[0];
+                                p0 = select4(early, e0, p0);
+                                if (CMAX == 8) {
+                                    const uint4 e1 = row[1];
+                                    p1 = select4(early, e1, p1);
                                 }
                             }
-#pragma unroll
-                            for (int w = 0; w < W; ++w) {
-                                pin(p0[w].x); pin(p0[w].y); pin(p0[w].z); pin(p0[w].w);
-                                if (CMAX == 8) { pin(p1[w].x); pin(p1[w].y); pin(p1[w].z); pin(p1[w].w); }
-                            }
-                            set_round_nearest(p0[0].x);
-#pragma unroll
-                            for (int w = 0; w < W; ++w) {
-                                if (w > 0) pin(p0[w].x);
-                                pin(p0[w].y); pin(p0[w].z); pin(p0[w].w);
-                                if (CMAX == 8) { pin(p1[w].x); pin(p1[w].y); pin(p1[w].z); pin(p1[w].w); }
-                            }
-#pragma unroll
-                            for (int w = 0; w < W; ++w) {
-                                if (have[w] || early[w]) {
-                                    if (STATS && c0 == 0) st_lf++;
-                                    pdf[0] = pdf[0] + __uint_as_float(p0[w].x); pdf[1] = pdf[1] + __uint_as_float(p0[w].y);
-                                    pdf[2] = pdf[2] + __uint_as_float(p0[w].z); pdf[3] = pdf[3] + __uint_as_float(p0[w].w);
-                                    if constexpr (CMAX == 8) {
-                                        pdf[4] = pdf[4] + __uint_as_float(p1[w].x); pdf[5] = pdf[5] + __uint_as_float(p1[w].y);
-                                        pdf[6] = pdf[6] + __uint_as_float(p1[w].z); pdf[7] = pdf[7] + __uint_as_float(p1[w].w);
-                                    }
-                                    any_leaf = true;
+                            pin(p0.x); pin(p0.y); pin(p0.z); pin(p0.w);
+                            if (CMAX == 8) { pin(p1.x); pin(p1.y); pin(p1.z); pin(p1.w); }
+                            set_round_nearest(p0.x);
+                            pin(p0.y); pin(p0.z); pin(p0.w);
+                            if (CMAX == 8) { pin(p1.x); pin(p1.y); pin(p1.z); pin(p1.w); }
+                            if (have || early) {
+                                if (STATS && c0 == 0) st_lf++;
+                                pdf[0] = pdf[0] + __uint_as_float(p0.x); pdf[1] = pdf[1] + __uint_as_float(p0.y);
+                                pdf[2] = pdf[2] + __uint_as_float(p0.z); pdf[3] = pdf[3] + __uint_as_float(p0.w);
+                                if constexpr (CMAX == 8) {
+                                    pdf[4] = pdf[4] + __uint_as_float(p1.x); pdf[5] = pdf[5] + __uint_as_float(p1.y);
+                                    pdf[6] = pdf[6] + __uint_as_float(p1.z); pdf[7] = pdf[7] + __uint_as_float(p1.w);
                                 }
+                                any_leaf = true;
                             }
-                            if (k0 + W < GROUP) {
+                            if (k0 + 1 < GROUP) {
 #pragma unroll
                                 for (int c = 0; c < CMAX; ++c) pin(pdf[c]);
                                 set_round_down(pdf[0]);
@@ -1067,6 +1009,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
                             }
                         }
                         continue;       // (next group of trees; the mode is round-to-nearest)
+                      }
                     }
                     // ---- level D-1 from the last-level table, one tree after the other: the node and both leaf PDFs of a
                     // tree come with one line fill and the side taken picks the PDF (every record of a usable table is an
@@ -1193,6 +1136,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5
             }
 
             if (TW) { tw_valid = true; tw_i = i; continue; }
+            if (DEEP && !live) continue;
             if (STATS) st_px++;
             if (a.keep_if_no_leaf && !any_leaf) {
                 if (a.fill_untouched) a.labels[i] = (uint16_t)kNoPixel;
@@ -1495,6 +1439,17 @@ inline unsigned long long now_ns()
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec;
+}
+
+// Launches that walk deep blocks (their waves fetch the blocks through LDS slabs): what is left for the depth tile, the node
+// table, the mailbox and the pixel list next to 8 KB of slab per wave -- two 512-thread or four 256-thread workgroups per CU.
+int coop_lds_budget(int block)
+{
+    const int knob = g_lds_budget;
+    if (knob > 0) return knob;
+    const int v = env_int("RDF_COOP_LDS_BUDGET", 0);
+    if (v > 0) return v;
+    return block == 512 ? 81920 - 65536 - 1024 : 40960 - 32768 - 1024;
 }
 
 int lds_budget(int block)
@@ -2042,8 +1997,25 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
 
-    // ---- LDS plan: [depth tile: th*twp*2 B, at address 0][node table: T*2^K*16 B][queue mailbox 32 B][pixel list] ----
-    const long long budget = lds_budget(tw ? 256 : block);
+    // deep blocks (k_eval_forest<..., DEEP>): from which root level on.  The knob or RDF_DEEP_FROM names a level (rounded up
+    // to a block root below, and never inside the levels LDS holds); nothing chosen: kUntunedDeepFrom.
+    int deep_from_wanted = 0;
+    if (packed && !tw && deep_bytes(n_trees, max_depth, n_classes) != 0) {
+        const int knob = g_deep_from;
+        deep_from_wanted = knob >= 0 ? knob : env_int("RDF_DEEP_FROM", -1);      // process-wide knob first,
+        if (deep_from_wanted < 0) deep_from_wanted = forest_deep_choice(packed);   // then what was chosen for this packed forest,
+        if (deep_from_wanted < 0) deep_from_wanted = kUntunedDeepFrom;             // else the heap-order records
+        const char *dp = reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes);
+        if ((reinterpret_cast<uintptr_t>(dp) & 127u) != 0) deep_from_wanted = 0;
+    }
+    // A launch that walks deep blocks fetches them by the WAVE, through a slab of 8 KB per wave in LDS (k_eval_forest<..., DEEP>): the
+    // slabs take 64 KB of a 512-thread workgroup (32 KB of a 256-thread one), so such a launch keeps a smaller depth tile and
+    // fewer levels in LDS and runs two (four) workgroups per CU instead of three (five).
+    const bool coop = deep_from_wanted > 0;
+    const long long slab_bytes = coop ? (long long)(block / 64) * 8192 : 0;
+
+    // ---- LDS plan: [depth tile: th*twp*2 B, at address 0][node table: T*2^K*16 B][queue mailbox 32 B][pixel list][slabs] ----
+    const long long budget = coop ? coop_lds_budget(block) : lds_budget(tw ? 256 : block);
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
     const bool compact_launch = packed && !stats && filter_class != -1 && compaction;
     // Halo and the levels that must stay in LDS, by measurement (profiles/r02_sweep_*.txt).  256-thread workgroups (32.7 KB):
@@ -2052,7 +2024,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // trees, 5 levels (11.45 ms; 6 + 48: 11.66).  With labels_reduce > 1 the halo shrinks until the tile fits.
     const bool many_trees = n_trees >= 8;
     // (labels_reduce 2, 64 frames, 512 threads: 6 levels + 32 px 0.81 ms, 7 + 40 0.89 ms -- a tile spans r times the pixels)
-    const int halo_default = block == 512 ? (r > 1 ? 32 : 56) : (many_trees ? kDefaultHalo + 8 : kDefaultHalo);
+    const int halo_default = coop ? (block == 512 ? 16 : 8)
+                                  : block == 512 ? (r > 1 ? 32 : 56) : (many_trees ? kDefaultHalo + 8 : kDefaultHalo);
     const int halo_knob = g_halo;
     int halo = halo_knob >= 0 ? halo_knob : env_int("RDF_HALO", halo_default);
     long long tile_bytes = 0;
@@ -2075,7 +2048,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // otherwise the tile may take what kMinLdsLevels levels of the forest leave: level for level, a level moved from LDS
     // to L1-resident global records costs less than the far probes a wider halo saves (measured: T4, 8 levels + 24 px
     // 5.26 ms, 7 levels + 32 px 5.17 ms, 6 levels + 40 px 5.6 ms on the bench batch)
-    const int k_min = many_trees ? kMinLdsLevels - 1 : (block == 512 && r == 1 ? kMinLdsLevels + 1 : kMinLdsLevels);
+    const int k_min = coop ? (many_trees ? kMinLdsLevels - 2 : kMinLdsLevels - 1)
+                           : many_trees ? kMinLdsLevels - 1 : (block == 512 && r == 1 ? kMinLdsLevels + 1 : kMinLdsLevels);
     const int k_floor = k_forced >= 0 ? k_forced : (max_depth < k_min ? max_depth : k_min);
     const long long tile_budget = budget - 32 - list_bytes - (k_floor > 0 ? (long long)n_trees * (1ll << k_floor) * 16 : 0);
     // 16-byte staging needs every row start 16-byte aligned in the image and in LDS
@@ -2114,31 +2088,26 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         const int pct = llt_knob == 1 ? 0 : env_int("RDF_LAST_LEVEL_MIN_PCT", 50);
         a.last_level_min = (uint32_t)((((unsigned long long)n_trees << (max_depth - 1)) * (unsigned long long)(pct < 0 ? 0 : pct > 100 ? 100 : pct)) / 100u);
     }
-    // deep blocks (k_eval_forest<..., DEEP>): from which root level on.  The knob or RDF_DEEP_FROM names a level (rounded up
-    // to a block root, and never inside the levels LDS holds); nothing chosen: kUntunedDeepFrom.
     bool deep_launch = false;
-    if (packed && !tw && deep_bytes(n_trees, max_depth, n_classes) != 0) {
+    if (deep_from_wanted > 0) {
         const int R0 = max_depth - deep_last_levels(a.cpad);
-        const int knob = g_deep_from;
-        int from = knob >= 0 ? knob : env_int("RDF_DEEP_FROM", -1);      // process-wide knob first,
-        if (from < 0) from = forest_deep_choice(packed);                 // then what was chosen for this packed forest,
-        if (from < 0) from = kUntunedDeepFrom;                           // else the heap-order records
-        if (from > 0) {
-            if (from < K) from = K;
-            if (from > R0) from = R0;
-            from = R0 - 3 * ((R0 - from) / 3);          // a root level: R0 - 3 i, rounded up
-            a.deep = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes));
-            a.deep_from = from;
-            deep_launch = (reinterpret_cast<uintptr_t>(a.deep) & 127u) == 0;
-            if (!deep_launch) a.deep = nullptr;
-        }
+        int from = deep_from_wanted;
+        if (from < K) from = K;
+        if (from > R0) from = R0;
+        from = R0 - 3 * ((R0 - from) / 3);          // a root level: R0 - 3 i, rounded up
+        a.deep = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes));
+        a.deep_from = from;
+        deep_launch = true;
     }
     const long long node_bytes = K > 0 ? (long long)n_trees * (1ll << K) * 16 : 0;
     a.lds_nodes_off = (uint32_t)tile_bytes;
     a.lds_mail_off = (uint32_t)(tile_bytes + node_bytes);
     a.lds_list_off = (uint32_t)(tile_bytes + node_bytes + 32);
     a.lds_xchg_off = a.lds_list_off;
-    const int lds_bytes = (int)(node_bytes + tile_bytes + 32 + list_bytes);
+    // (the slabs start on a 1-KB boundary: an LDS-DMA piece is 1 KB)
+    const long long slab_at = (tile_bytes + node_bytes + 32 + list_bytes + 1023) & ~1023ll;
+    a.lds_slab_off = (uint32_t)slab_at;
+    const int lds_bytes = coop ? (int)(slab_at + slab_bytes) : (int)(node_bytes + tile_bytes + 32 + list_bytes);
     if (plan_only) {
         plan_only->a = a;
         plan_only->lds_bytes = lds_bytes;

@@ -205,7 +205,7 @@ def roofline_for(leg, key, live, kernel_ms, alg_bytes, useful=None):
         if com:
             vals, kern = com.get("counters"), com.get("kernel")
             src = f"{com.get('_file')} (committed; this run collected none)"
-    r = roofline.model(vals, kernel_ms, alg_bytes, useful=useful)
+    r = roofline.model(vals, kernel_ms, alg_bytes, useful=useful, kernel_name=kern)
     r["kernel"] = kern or "k_eval_forest"
     r["counters_source"] = src
     r["counters"] = {k: (int(v) if v == int(v) else round(v, 1)) for k, v in (vals or {}).items() if not k.startswith("_")}
@@ -260,7 +260,8 @@ def compact_line(out, full_path=None):
              "kernel": _short_kernel(r.get("kernel")), "kernel_ms": r.get("kernel_ms"),
              "hbm_frac": g(lv, "hbm", "frac"), "hbm_gbs": g(lv, "hbm", "achieved"), "hbm_peak_gbs": g(lv, "hbm", "peak"),
              "l2_l1_frac": g(lv, "l2_l1", "frac"), "l1_ta_frac": g(lv, "l1_ta", "frac"),
-             "ta_busy_frac_counter": g(lv, "l1_ta", "ta_busy_frac_counter"), "valu_frac": g(lv, "valu", "frac"),
+             "ta_busy_frac_counter": g(lv, "l1_ta", "ta_busy_frac_counter"), "ta_busy_model": g(lv, "l1_ta", "ta_busy_model"),
+             "hbm_frac_of_gather_ceiling": g(lv, "hbm", "frac_of_gather_ceiling"), "valu_frac": g(lv, "valu", "frac"),
              "l2_hit_rate": r.get("l2_hit_rate"), "clock_ghz": r.get("clock_ghz"),
              "algorithmic_bytes": g(r, "algorithmic", "bytes_per_launch"), "algorithmic_gbs": g(r, "algorithmic", "rate_gbs"),
              "algorithmic_over_hbm_peak": g(r, "algorithmic", "over_hbm_peak"),
@@ -301,6 +302,8 @@ def compact_line(out, full_path=None):
         "cfg5_balanced_frac": g(out, "cfg5_balanced", "roofline", "frac"),
         "cfg5_balanced_hbm_frac": g(out, "cfg5_balanced", "roofline", "levels", "hbm", "frac"),
         "cfg5_balanced_ta_busy": g(out, "cfg5_balanced", "roofline", "levels", "l1_ta", "ta_busy_frac_counter"),
+        "cfg5_balanced_frac_of_gather_ceiling": g(out, "cfg5_balanced", "roofline", "levels", "hbm", "frac_of_gather_ceiling"),
+        "balanced_frac_of_gather_ceiling": g(out, "cfg2_balanced", "batch", "roofline", "levels", "hbm", "frac_of_gather_ceiling"),
         "cfg5_balanced_deep_from": g(out, "cfg5_balanced", "tune", "deep_from"),
         "cfg5_balanced_differing_pixels": g(out, "cfg5_balanced", "parity", "differing_pixels"),
         "pcie_inclusive_mpix": g(out, "pcie_inclusive", "value"),

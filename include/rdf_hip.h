@@ -432,10 +432,10 @@ void rdf_set_last_level_table(int on);   /* packed forests of up to four classes
                                             0: never */
 
 void rdf_set_deep_from(int level);       /* packed forests of up to eight classes can walk their deep levels from the deep blocks
-                                            (three levels per 128-byte line, one tree after the other): -1 = the library's
-                                            choice by forest size, 0 = never, > 0 = from this level on (rounded up to a block
-                                            root; never inside the levels held in LDS).  Same labels either way. */
-
+                                            (three levels per 128-byte line, one tree after the other, the wave fetching its
+                                            lanes' blocks together): -1 = each table's own choice (rdf_forest_set_deep_from /
+                                            rdf_forest_tune; none: never), 0 = never, > 0 = from this level on (rounded up to a
+                                            block root; never inside the levels held in LDS).  Same labels either way. */
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
 int rdf_event_create(void **event);
 int rdf_event_record(void *event, void *stream);

@@ -52,11 +52,11 @@ def test_binding_table_matches_header(rdf):
     assert lib.rdf_forest_packed_bytes(3, 10, 5) == up128((3 << 10) * (16 + 64)) + deep(3, 10, 1) * 128 + 128
     assert lib.rdf_forest_packed_bytes(3, 10, 9) == up128((3 << 10) * (16 + 96)) + 128
     assert lib.rdf_forest_packed_bytes(0, 10, 4) == 0 and lib.rdf_forest_packed_bytes(4, 0, 4) == 0
-    # deep blocks only while a lane's 32-bit offset reaches every line: (lines + 2^R0) x 128 < 2^32 -- T6/D24 yes, T7 / T8 at D24 no
+    # deep blocks for forests of 5 to 24 levels and up to eight classes, whatever the number of trees
     lib.rdf_forest_packed_bytes.restype, lib.rdf_forest_packed_bytes.argtypes = ctypes.c_size_t, [ctypes.c_int] * 3
-    assert lib.rdf_forest_packed_bytes(6, 24, 4) == up128((6 << 24) * (16 + 32) + (6 << 23) * 64 + 64) + deep(6, 24, 2) * 128 + 128
-    for T in (7, 8):
-        assert lib.rdf_forest_packed_bytes(T, 24, 4) == up128((T << 24) * (16 + 32) + (T << 23) * 64 + 64) + 128
+    for T in (6, 8):
+        assert lib.rdf_forest_packed_bytes(T, 24, 4) == up128((T << 24) * (16 + 32) + (T << 23) * 64 + 64) + deep(T, 24, 2) * 128 + 128
+    assert lib.rdf_forest_packed_bytes(2, 25, 4) == up128((2 << 25) * (16 + 32) + (2 << 24) * 64 + 64) + 128
     assert lib.rdf_forest_packed_bytes(8, 22, 4) == up128((8 << 22) * (16 + 32) + (8 << 21) * 64 + 64) + deep(8, 22, 2) * 128 + 128
     assert b"2^31" in lib.rdf_error_string(-3)
 

@@ -1538,12 +1538,13 @@ def _spine_forest(T, D, C, spine_trees):
     return f, rows
 
 
-@pytest.mark.parametrize("T,deep", [(6, True), (8, False)])
-def test_depth_24_forests_and_the_32_bit_block_offsets(rdf, oracle, gpu_runtime, T, deep):
-    """The deep walk addresses a block as 64-bit base + 32-bit offset; a finished lane's offset points at the zero line behind
-    the LAST block, which only fits while the whole table stays under 4 GiB.  T6/D24/C4 (3.7 GB of blocks, offsets up to
-    2^32 - 2^26) walks the blocks with finished and walking lanes side by side in every wave; T8/D24/C4 (4.9 GB) gets no deep
-    blocks at all (round 4 let the offset wrap there) and is walked from the heap-order records.  Labels are the oracle's."""
+@pytest.mark.parametrize("T", [6, 8])
+def test_depth_24_forests_walk_their_deep_blocks(rdf, oracle, gpu_runtime, T):
+    """The deep walk addresses a block as 64-bit base + 32-bit offset (heap index x 128): the deepest forests that get deep
+    blocks, T6 and T8 at D24 (3.7 and 4.9 GB of blocks: block offsets up to 2^30, table offsets beyond 2^32 -- round 4 pointed
+    finished lanes at a zero line behind the last block with a 32-bit difference that wrapped for T8/D24; now a finished lane
+    names the first block of its tree's level).  Every wave holds finished and walking lanes side by side.  Labels are the oracle's."""
+    deep = True
     lib = gpu_runtime.lib
     D, C = 24, 4
     with_deep = lib.rdf_forest_packed_bytes(T, D, C)

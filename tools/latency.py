@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--trees", type=int, default=4)
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--n", type=int, default=300)
+    ap.add_argument("--deep", type=int, nargs="*", default=None, help="compare the deep-block walks from these root levels instead")
     a = ap.parse_args()
     import torch
     rdf = importlib.import_module("3d-beats_amd")
@@ -33,10 +34,17 @@ def main():
     r = a.reduce
     labels = rdf.DeviceArray((1, 480 // r, 848 // r), np.uint16).fill(65535)
     ev = rdf.DecisionTreeEvaluator()
+    ev.auto_tune = False
     variants = [("default", {}), ("tree waves off", {"tree_waves": 0}), ("rows per wave 2", {"rows_per_wave": 2}),
                 ("512 threads", {"block_threads": 512}), ("halo 16", {"halo": 16}), ("halo 24", {"halo": 24}),
                 ("lds levels 6", {"lds_levels": 6}), ("lds levels 8", {"lds_levels": 8})]
-    defaults = {"tree_waves": -1, "rows_per_wave": 0, "block_threads": 0, "halo": -1, "lds_levels": -1}
+    if a.deep:      # the deep-block walk of a small launch, by take-over level and geometry
+        variants = [("heap-order records", {"deep_from": 0})]
+        for lvl in a.deep:
+            variants += [(f"deep {lvl}", {"deep_from": lvl}), (f"deep {lvl} 512 threads", {"deep_from": lvl, "block_threads": 512}),
+                         (f"deep {lvl} halo 16", {"deep_from": lvl, "halo": 16, "lds_budget_bytes": 21000}),
+                         (f"deep {lvl} rows 2", {"deep_from": lvl, "rows_per_wave": 2})]
+    defaults = {"tree_waves": -1, "rows_per_wave": 0, "block_threads": 0, "halo": -1, "lds_levels": -1, "deep_from": -1, "lds_budget_bytes": 0}
     ref = None
     for name, knobs in variants:
         for k, v in {**defaults, **knobs}.items():

@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$OUT
 pass() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT/$name -- python3 $R/bench.py $ARGS \
+  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT/$name -- python3 $R/bench.py $ARGS \
       > $R/gpurun_out/$OUT/$name.json 2> $R/gpurun_out/$OUT/$name.err || echo "pass $name failed rc=$?"
 }
 pass fetch  FETCH_SIZE TCC_HIT_sum

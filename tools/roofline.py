@@ -23,6 +23,18 @@ MI355X_MICROARCH.md for the peaks):
     constants (0.6 per hit + 2.35 per fill, added up, cycles derived from wall time at an assumed 2.4 GHz) overstated
     this level by 15-25 % at the kernel's fill share of about one half and put it above 1.0 once the kernel got faster;
     the curve agrees with the hardware's own TA_TA_BUSY (0.78 against 0.79 on the bench batch).
+  * The memory side's CEILING for the walk's own access pattern -- every lane one random 128-byte line, the next one depending
+    on the data (tools/ubench_gather.hip, profiles/r05_ubench_gather.txt): 7.1-7.2 TB/s from a 146-MB and a 1.2-GB table, 6.5 TB/s
+    from a 4-GB one, with the wave fetching its lines by LDS-DMA (16 or 8 waves per CU) as with one load per lane (24 waves):
+    the `hbm` level carries `frac_of_gather_ceiling` beside its fraction of the 8 TB/s data-sheet peak.
+  * TA_TA_BUSY is NOT a utilisation of the L1's line rate once fills miss the L2: at that ceiling the counter reads 0.90 (LDS-DMA
+    gather, 0.20 line accesses per CU and cycle) and 0.98 (seven loads per lane, 0.63 per cycle) while the L1 serves 1.7 hits
+    per cycle -- a texture addresser whose requests wait for the fabric counts as busy (6.5-6.9 busy cycles per line that
+    misses the L2, at the ceiling).  `ta_busy_model` therefore adds, to the L1 level's cycles, a price per L2 miss of the
+    launch (TCC_MISS): 5.6 cycles for kernels whose misses are divergent 16-byte record loads, 3.5 for the deep-block kernels,
+    whose misses are whole lines fetched by the wave -- two constants FITTED on round 5's five legs (below the ceiling a miss
+    queues for less long than at it), which put the model within 8 % of the counter on all of them; round 4's model, without the
+    term, read 0.60 and 0.46 where the counter read 0.94 and 0.97.
   * VALU issue with more than one wave per SIMD: 2.35 cycles for the simple integer/fp32 instructions, 4.2 cycles for
     v_pk_*_f32, conversions, v_perm_b32 and the three-operand integer forms (tools/ubench_valu.hip); the kernel's mix is
     counted in its ISA (VALU_MIX below).
@@ -39,6 +51,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBS = 8000.0          # spec, MI355X_MICROARCH.md
+GATHER_CEILING_GBS = 7150.0    # random dependent 128-byte line gather, tables of 146 MB to 1.2 GB (profiles/r05_ubench_gather.txt)
+TA_BUSY_CYCLES_PER_L2_MISS = {"divergent": 5.6, "deep": 3.5}     # fitted on profiles/r05_bench.json's five legs (see the docstring)
 L2_L1_BYTES_PER_CLK_PER_CU = 64.0
 LINE = 128
 CUS = 256
@@ -131,7 +145,15 @@ def l1_cycles_per_access(share):
     return pts[-1][1]
 
 
-def model(counters, kernel_ms, alg_bytes=None, cus=CUS, useful=None):
+def is_deep_kernel(kernel_name):
+    """k_eval_forest<BLOCK, PACKED, CMAX, STATS, GROUP, COMPACT, NL, TW, DEEP>: the last template argument."""
+    if not kernel_name or "k_eval_forest<" not in kernel_name:
+        return False
+    args = kernel_name.split("k_eval_forest<", 1)[1].split(">", 1)[0].split(",")
+    return len(args) >= 9 and args[8].strip() == "true"
+
+
+def model(counters, kernel_ms, alg_bytes=None, cus=CUS, useful=None, kernel_name=None):
     """The four levels for one launch; returns the `roofline` object of bench.py's JSON line.
 
     `useful` (rdf_eval_forest_packed_stats, the same launch with counters on): {"records", "leaf_rows", "far_probes",
@@ -163,6 +185,7 @@ def model(counters, kernel_ms, alg_bytes=None, cus=CUS, useful=None):
         hbm = rd_bytes + c["WRITE_SIZE"] * 1024.0
         a = hbm / t / 1e9
         levels["hbm"] = {"achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                         "gather_ceiling": GATHER_CEILING_GBS, "frac_of_gather_ceiling": round(a / GATHER_CEILING_GBS, 4),
                          "bytes_per_launch": int(hbm),
                          "what": "L2 fabric-side read requests x 128 B + WRITE_SIZE (Infinity-Cache hits included)"}
     # ---- L2 -> L1 line fills ----
@@ -187,6 +210,12 @@ def model(counters, kernel_ms, alg_bytes=None, cus=CUS, useful=None):
                                                     if c.get("TA_TA_BUSY_sum") and c.get("_ns:TA_TA_BUSY_sum") else None),
                            "what": "L1 line accesses x the measured cycles per access at this launch's fill share "
                                    "(tools/ubench_l1_fill.hip) per CU against the kernel's cycles"}
+        if c.get("TCC_MISS_sum") is not None:
+            kind = "deep" if is_deep_kernel(kernel_name) else "divergent"
+            busy = (ta_cycles + c["TCC_MISS_sum"] * TA_BUSY_CYCLES_PER_L2_MISS[kind] / cus) / cyc
+            levels["l1_ta"].update({"ta_busy_model": round(busy, 4), "ta_busy_model_what":
+                                    f"the level's cycles + {TA_BUSY_CYCLES_PER_L2_MISS[kind]} busy cycles per L2 miss ({kind} loads): what "
+                                    "TA_TA_BUSY should read -- the counter includes the time requests wait for the fabric"})
         if useful:
             lines = float(sum(useful.get(k, 0) for k in ("records", "leaf_rows", "far_probes", "blocks")))
             levels["l1_ta"].update({

@@ -47,6 +47,7 @@ def main():
     red = a.reduce
     labels = rdf.DeviceArray((host.shape[0], host.shape[1] // red, host.shape[2] // red), np.uint16).fill(65535)
     ev = rdf.DecisionTreeEvaluator(use_packed=not a.unpacked)
+    ev.auto_tune = False        # (the combos say which table is walked)
     filt = None
     if a.filter:
         yy, xx = np.mgrid[0:host.shape[1] // red, 0:host.shape[2] // red]
