@@ -1895,7 +1895,7 @@ Knob g_last_level_table{-1};                    // -1: level D-1 from the last-l
 struct Plan {
     EvalArgs a;
     int lds_bytes = 0, block = 0;
-    bool big = false, empty = false, tw = false;
+    bool big = false, empty = false, tw = false, deep = false;
 };
 
 int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
@@ -1964,6 +1964,18 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     const bool filtered_r1 = packed && filter_class != -1 && compaction && r == 1;
     if (block != 256 && block != 512) block = (big && !filtered_r1) ? 512 : 256;   // (other requests: the default)
     if (stats && !packed) block = 256;      // (the packed visit-counter kernels take the geometry of the launch they describe)
+    // deep blocks (k_eval_forest<..., DEEP>): from which root level on.  The knob or RDF_DEEP_FROM names a level (rounded up
+    // to a block root below, and never inside the levels LDS holds); nothing chosen: kUntunedDeepFrom.  (Tree-wave launches
+    // never walk them: see below.)
+    int deep_from_wanted = 0;
+    if (packed && deep_bytes(n_trees, max_depth, n_classes) != 0) {
+        const int knob = g_deep_from;
+        deep_from_wanted = knob >= 0 ? knob : env_int("RDF_DEEP_FROM", -1);      // process-wide knob first,
+        if (deep_from_wanted < 0) deep_from_wanted = forest_deep_choice(packed);   // then what was chosen for this packed forest,
+        if (deep_from_wanted < 0) deep_from_wanted = kUntunedDeepFrom;             // else the heap-order records
+        const char *dp = reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes);
+        if ((reinterpret_cast<uintptr_t>(dp) & 127u) != 0) deep_from_wanted = 0;
+    }
     const int rpw_knob = g_rows_per_wave;
     int rpw = rpw_knob > 0 ? rpw_knob : env_int("RDF_ROWS_PER_WAVE", 0);
     if (rpw < 1 || rpw > kMaxRowsPerWave) {
@@ -1974,6 +1986,9 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
             // (848x480 frames: 4 in a launch 0.237 -> 0.212 ms, 8: 0.378 -> 0.362, 16: 0.696 -> 0.677; 24: 0.937 vs 0.952)
             const long long tiles2 = (long long)n_img * a.tiles_x * ((a.Hl + 15) / 16);
             rpw = tiles2 >= 30ll * di.cus ? 2 : 1;
+            // (deep blocks, eight trees and more: 8-row tiles leave the 15 KB beside the slabs to a 24-pixel halo -- config 5's
+            // shard on a balanced forest 18.5 -> 18.0 ms, profiles/r05_deep_coop.txt section 7)
+            if (deep_from_wanted > 0 && n_trees >= 8) rpw = 1;
         }
         while (rpw > 1 && (long long)n_img * a.tiles_x * ((a.Hl + rpw - 1) / rpw) < waves_wanted) rpw >>= 1;
     }
@@ -1997,17 +2012,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
 
-    // deep blocks (k_eval_forest<..., DEEP>): from which root level on.  The knob or RDF_DEEP_FROM names a level (rounded up
-    // to a block root below, and never inside the levels LDS holds); nothing chosen: kUntunedDeepFrom.
-    int deep_from_wanted = 0;
-    if (packed && !tw && deep_bytes(n_trees, max_depth, n_classes) != 0) {
-        const int knob = g_deep_from;
-        deep_from_wanted = knob >= 0 ? knob : env_int("RDF_DEEP_FROM", -1);      // process-wide knob first,
-        if (deep_from_wanted < 0) deep_from_wanted = forest_deep_choice(packed);   // then what was chosen for this packed forest,
-        if (deep_from_wanted < 0) deep_from_wanted = kUntunedDeepFrom;             // else the heap-order records
-        const char *dp = reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes);
-        if ((reinterpret_cast<uintptr_t>(dp) & 127u) != 0) deep_from_wanted = 0;
-    }
+    if (tw) deep_from_wanted = 0;
     // A launch that walks deep blocks fetches them by the WAVE, through a slab of 8 KB per wave in LDS (k_eval_forest<..., DEEP>): the
     // slabs take 64 KB of a 512-thread workgroup (32 KB of a 256-thread one), so such a launch keeps a smaller depth tile and
     // fewer levels in LDS and runs two (four) workgroups per CU instead of three (five).
@@ -2024,7 +2029,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // trees, 5 levels (11.45 ms; 6 + 48: 11.66).  With labels_reduce > 1 the halo shrinks until the tile fits.
     const bool many_trees = n_trees >= 8;
     // (labels_reduce 2, 64 frames, 512 threads: 6 levels + 32 px 0.81 ms, 7 + 40 0.89 ms -- a tile spans r times the pixels)
-    const int halo_default = coop ? (block == 512 ? 16 : 8)
+    const int halo_default = coop ? (block == 512 ? (many_trees ? 24 : 16) : 8)
                                   : block == 512 ? (r > 1 ? 32 : 56) : (many_trees ? kDefaultHalo + 8 : kDefaultHalo);
     const int halo_knob = g_halo;
     int halo = halo_knob >= 0 ? halo_knob : env_int("RDF_HALO", halo_default);
@@ -2048,7 +2053,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     // otherwise the tile may take what kMinLdsLevels levels of the forest leave: level for level, a level moved from LDS
     // to L1-resident global records costs less than the far probes a wider halo saves (measured: T4, 8 levels + 24 px
     // 5.26 ms, 7 levels + 32 px 5.17 ms, 6 levels + 40 px 5.6 ms on the bench batch)
-    const int k_min = coop ? (many_trees ? kMinLdsLevels - 2 : kMinLdsLevels - 1)
+    const int k_min = coop ? (many_trees ? kMinLdsLevels - 2 : kMinLdsLevels - 1)       // (4 and 5 levels)
                            : many_trees ? kMinLdsLevels - 1 : (block == 512 && r == 1 ? kMinLdsLevels + 1 : kMinLdsLevels);
     const int k_floor = k_forced >= 0 ? k_forced : (max_depth < k_min ? max_depth : k_min);
     const long long tile_budget = budget - 32 - list_bytes - (k_floor > 0 ? (long long)n_trees * (1ll << k_floor) * 16 : 0);
@@ -2114,6 +2119,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         plan_only->block = block;
         plan_only->big = big;
         plan_only->tw = tw;
+        plan_only->deep = deep_launch;
         return RDF_OK;
     }
 
@@ -2429,7 +2435,8 @@ static int layered_run(const uint16_t *depth, int dim_x, int dim_y, int n_layers
                                            /*fill_untouched=*/1, &plans[i], /*allow_tw=*/pass == 0);
                 if (rc != RDF_OK) return rc;
                 const Plan &pl = plans[i];
-                ok = !pl.empty && !pl.big && (pl.block == 256 || pl.tw) && pl.a.rows_per_wave < kMaxRowsPerWave &&
+                // (a layer whose table walks deep blocks takes a launch of its own: the kernel of several layers has no slabs)
+                ok = !pl.empty && !pl.big && !pl.deep && (pl.block == 256 || pl.tw) && pl.a.rows_per_wave < kMaxRowsPerWave &&
                      pl.a.rows_per_wave == plans[0].a.rows_per_wave && (pl.tw || pl.a.n_tiles == plans[0].a.n_tiles);
                 n_tw += pl.tw ? 1 : 0;
                 cmax = n_classes[i] > 4 ? 8 : cmax;

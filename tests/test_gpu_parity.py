@@ -802,6 +802,39 @@ def test_layers_in_one_launch_equal_the_filtered_sequence(one_launch, tree_waves
         lib.rdf_set_tree_waves(-1)
 
 
+@pytest.mark.parametrize("tree_waves", [0, 1])
+def test_layered_run_with_a_layer_whose_table_walks_deep_blocks(tree_waves, rdf, gpu_runtime, oracle):
+    """A stack whose first layer's packed table carries a deep-level choice: the layers-in-one-launch kernel has no block slabs, so
+    such a layer takes a launch of its own (tree waves, when on, come first and walk no deep blocks) -- the per-layer label
+    images and the composite are the oracle's chain either way."""
+    synth = rdf.synth
+    lib = gpu_runtime.lib
+    h, w, r, s_ = 240, 424, 2, 0.5
+    forests = [synth.forest(4, 11, 4, "balanced", 300, calib=synth.calibration_frames(3, 120, 212)), synth.forest(3, 9, 4, "trained", 310)]
+    conditions = [[0, 1], [0, 2], [1, 3], [0, 3], [0, 4], [0, 5], [0, 6]]
+    models = [rdf.DecisionForest.from_numpy(f) for f in forests]
+    cfg = {"layers": [{"model": models[0]}, {"model": models[1], "filter_model": 0, "filter_model_class": 3}],
+           "conditions": conditions, "label_colors": [[i, i, i, 255] for i in range(6)]}
+    assert lib.rdf_forest_set_deep_from(models[0].packed(s_).ptr, 6) == 0 and models[0].deep_from(s_) == 6
+    lib.rdf_set_tree_waves(tree_waves)
+    try:
+        lf = rdf.LayeredDecisionForest(cfg, (h, w), r)
+        dbuf, lbuf = rdf.GpuBuffer((h, w), np.uint16), rdf.GpuBuffer((h // r, w // r), np.uint16)
+        for frame in synth.frames(["live", "dense"], 960, h, w):
+            dbuf.cu().set(frame)
+            lf.run(dbuf, lbuf, s_)
+            shape = (1, h // r, w // r)
+            l0, l1, comp = (np.full(shape, 65535, np.uint16) for _ in range(3))
+            oracle.eval_forest(frame[None], forests[0], l0, r, None, None, s_)
+            oracle.eval_forest(frame[None], forests[1], l1, r, l0, 3, s_)
+            oracle.composite([l0[0], l1[0]], np.array(conditions, np.int32), comp)
+            assert np.array_equal(lf.label_images[0].cu().get().reshape(shape), l0)
+            assert np.array_equal(lf.label_images[1].cu().get().reshape(shape), l1)
+            assert np.array_equal(lbuf.cu().get().reshape(shape), comp)
+    finally:
+        lib.rdf_set_tree_waves(-1)
+
+
 @pytest.mark.parametrize("one_launch", [1, 0])
 def test_filter_class_minus_one_means_no_filter(one_launch, rdf, gpu_runtime, oracle):
     """A layer that names a filter layer but the filter class -1 is evaluated everywhere (tree_eval.cu:81: the filter is

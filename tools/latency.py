@@ -37,14 +37,22 @@ def main():
     ev.auto_tune = False
     variants = [("default", {}), ("tree waves off", {"tree_waves": 0}), ("rows per wave 2", {"rows_per_wave": 2}),
                 ("512 threads", {"block_threads": 512}), ("halo 16", {"halo": 16}), ("halo 24", {"halo": 24}),
-                ("lds levels 6", {"lds_levels": 6}), ("lds levels 8", {"lds_levels": 8})]
+                ("lds levels 6", {"lds_levels": 6}), ("lds levels 8", {"lds_levels": 8}),
+                # more, smaller workgroup footprints: every tile of the frame resident at once (one round instead of 1.3)
+                ("2 trees/lane, 23 KB, halo 24", {"group": 2, "lds_budget_bytes": 23000, "halo": 24}),
+                ("2 trees/lane, 23 KB, halo 24, 6 levels", {"group": 2, "lds_budget_bytes": 23000, "halo": 24, "lds_levels": 6}),
+                ("2 trees/lane, 23 KB, halo 16", {"group": 2, "lds_budget_bytes": 23000, "halo": 16}),
+                ("2 trees/lane, default LDS", {"group": 2}),
+                ("1 tree/lane, 20 KB, halo 16", {"group": 1, "lds_budget_bytes": 20000, "halo": 16}),
+                ("1 tree/lane, 20 KB, halo 24, 6 levels", {"group": 1, "lds_budget_bytes": 20000, "halo": 24, "lds_levels": 6}),
+                ("4 trees/lane, 26 KB, halo 24", {"lds_budget_bytes": 26000, "halo": 24})]
     if a.deep:      # the deep-block walk of a small launch, by take-over level and geometry
         variants = [("heap-order records", {"deep_from": 0})]
         for lvl in a.deep:
             variants += [(f"deep {lvl}", {"deep_from": lvl}), (f"deep {lvl} 512 threads", {"deep_from": lvl, "block_threads": 512}),
                          (f"deep {lvl} halo 16", {"deep_from": lvl, "halo": 16, "lds_budget_bytes": 21000}),
                          (f"deep {lvl} rows 2", {"deep_from": lvl, "rows_per_wave": 2})]
-    defaults = {"tree_waves": -1, "rows_per_wave": 0, "block_threads": 0, "halo": -1, "lds_levels": -1, "deep_from": -1, "lds_budget_bytes": 0}
+    defaults = {"tree_waves": -1, "rows_per_wave": 0, "block_threads": 0, "halo": -1, "lds_levels": -1, "deep_from": -1, "lds_budget_bytes": 0, "group": 0}
     ref = None
     for name, knobs in variants:
         for k, v in {**defaults, **knobs}.items():
