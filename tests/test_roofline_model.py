@@ -76,3 +76,41 @@ def test_useful_fraction_never_exceeds_the_utilisation(roofline):
             ta = r["levels"]["l1_ta"]
             assert ta["useful_line_accesses_per_launch"] <= ta["l1_line_accesses_per_launch"]
             assert ta["useful_frac"] <= ta["frac"] <= 1.0
+
+
+def test_ta_busy_model_follows_the_counter_on_round_fives_five_legs(roofline):
+    """TA_TA_BUSY is not a utilisation of the L1's line rate once fills miss the L2 (at the fabric's ceiling the counter reads
+    0.90-0.98 while the L1 handles a fifth of its rate: profiles/r05_ubench_gather.txt), so the model of what the counter
+    should read adds a price per L2 miss to the L1 level's cycles.  On the committed round-5 line it is within 10 % of the
+    counter on all five legs -- round 4's model, without the term, read 0.60 and 0.46 against 0.94 and 0.97 on the deep legs --
+    and recomputing it here from the committed counters gives the committed figure."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    legs = {"headline": line["roofline"], "cfg2": line["cfg2_single_frame"]["roofline"], "cfg5": line["cfg5_shard"]["roofline"],
+            "headline_balanced": line["cfg2_balanced"]["batch"]["roofline"], "cfg5_balanced": line["cfg5_balanced"]["roofline"]}
+    for name, r in legs.items():
+        ta = r["levels"]["l1_ta"]
+        assert ta["ta_busy_frac_counter"] and ta["ta_busy_model"], name
+        assert abs(ta["ta_busy_model"] / ta["ta_busy_frac_counter"] - 1.0) < 0.10, (name, ta["ta_busy_model"], ta["ta_busy_frac_counter"])
+        assert ta["ta_busy_model"] >= ta["frac"]                    # the L1 level's own cycles are part of it
+        deep = roofline.is_deep_kernel(r["kernel"])       # (config 5's "full" forest: the tuner may take the last blocks, by 2 %)
+        assert deep or not name.endswith("balanced"), (name, r["kernel"])
+        assert not deep or name != "headline", (name, r["kernel"])
+        per_miss = roofline.TA_BUSY_CYCLES_PER_L2_MISS["deep" if deep else "divergent"]
+        cyc = ta["peak"] * 1e6
+        again = ta["frac"] + r["counters"]["TCC_MISS_sum"] * per_miss / roofline.CUS / cyc
+        assert again == pytest.approx(ta["ta_busy_model"], abs=2e-3), name
+        # the fabric level: the data-sheet peak (the contract's figure) and the measured ceiling of the walk's own access pattern
+        hbm = r["levels"]["hbm"]
+        assert hbm["gather_ceiling"] == roofline.GATHER_CEILING_GBS and hbm["frac_of_gather_ceiling"] == pytest.approx(
+            hbm["achieved"] / roofline.GATHER_CEILING_GBS, abs=1e-3)
+        assert hbm["frac"] < hbm["frac_of_gather_ceiling"] <= 1.0
+    # the deep legs are bound by the fabric or within a few per cent of it, and nowhere near 1 on the L1's own line rate
+    b, c5 = legs["headline_balanced"], legs["cfg5_balanced"]
+    assert c5["bound"] == "hbm" and c5["levels"]["hbm"]["frac_of_gather_ceiling"] > 0.75
+    assert b["levels"]["hbm"]["frac"] > 0.6 and b["levels"]["l1_ta"]["frac"] < 0.75
+
+
+def test_kernel_name_tells_the_deep_walk(roofline):
+    assert roofline.is_deep_kernel("void (anonymous namespace)::k_eval_forest<512, true, 4, false, 4, false, 1, false, true>((anonymous namespace)::EvalArgsN<1>)")
+    assert not roofline.is_deep_kernel("void (anonymous namespace)::k_eval_forest<512, true, 4, false, 4, false, 1, false, false>((anonymous namespace)::EvalArgsN<1>)")
+    assert not roofline.is_deep_kernel("k_eval_forest") and not roofline.is_deep_kernel(None)
