@@ -9,8 +9,9 @@ short).  The ratio of the two timings is the zero-overhead bound of lane refill,
 
 The experiment's code is not in the product source: it is kept as profiles/r04_refill_bound.patch (round 5 moved it out).
 
-    patch -p1 < profiles/r04_refill_bound.patch        (on a scratch copy of the tree)
-    hipcc ... -DRDF_EXPERIMENT_REFILL_BOUND -o tools/bin/librdf_refill_bound.so <the four .hip files>
+
+    git show 585fd4a:3d-beats_amd/csrc/rdf_hip.hip > (scratch tree)/3d-beats_amd/csrc/rdf_hip.hip
+    hipcc ... -DRDF_EXPERIMENT_REFILL_BOUND -o tools/bin/librdf_refill_bound.so <the four .hip files of the scratch tree>
     python3 tools/refill_bound_gpu.py [--topology trained] [--frames 128]
 """
 import argparse
