@@ -63,6 +63,12 @@ def block():
         f"**{b['batch']['value']} Mpix/s, {b['batch']['ms_per_step']} ms** (round 4: 6 585–6 766 Mpix/s, 7.70–7.91 ms; heap-order records: 11.2 ms); tuned: deep blocks from level {b['tune']['deep_from']} "
         f"(sample: {b['tune']['tried']}); one dense frame {round(b['kernel_ms'] * 1e3, 1)} µs (round 4: 138); {b['parity']['frames_checked']} frames against the oracle: {b['parity']['differing_pixels']} differing pixels",
         "`cfg2_balanced`, `value_balanced`")
+    ksb = kernel_stats("r05_kernel_stats_balanced.csv")
+    if ksb:
+        trb = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_under_rocprof_balanced.json")))
+        row("its kernel under `rocprofv3 --kernel-trace --stats` (`--topology balanced --deep-from 12`)",
+            f"{ksb['avg_ms']:.3f} ms average over {ksb['calls']} launches (min {ksb['min_ms']:.3f}, max {ksb['max_ms']:.3f}) of `{ksb['kernel']}`; hipEvent median of that run {trb['ms_per_step']} ms",
+            "`profiles/r05_kernel_stats_balanced.csv`, `profiles/r05_bench_under_rocprof_balanced.json`")
     bh, bt = br["levels"]["hbm"], br["levels"]["l1_ta"]
     row("its roofline",
         f"fabric side **{bh['bytes_per_launch'] / 1e9:.1f} GB per launch = {bh['achieved']} GB/s = {bh['frac']} of 8 TB/s, {bh['frac_of_gather_ceiling']} of the {bh['gather_ceiling']:.0f} GB/s a pure gather of random lines reaches**; "
