@@ -1805,8 +1805,14 @@ int packed_info(const void *packed, const void *info_dev, void *stream, PackedSt
     st.scale = host.scale;
     st.info_dev = info_dev;
     // the choice the table carries (made by whoever tuned it, in this process or another), unless this process made one since
+    // (rdf_forest_set_deep_from on a table it had not looked at yet): that one goes into the table now
+    uint32_t write_word = 0u;
     if (st.deep_from < 0 && host.deep_choice != 0u && host.deep_choice <= 31u) st.deep_from = (int)host.deep_choice - 1;
+    else if (st.deep_from >= 0 && host.deep_choice != (uint32_t)st.deep_from + 1u) write_word = (uint32_t)(st.deep_from > 30 ? 30 : st.deep_from) + 1u;
     *out = st;
+    if (write_word != 0u)
+        (void)hipMemcpy(reinterpret_cast<char *>(const_cast<void *>(info_dev)) + offsetof(PackInfo, deep_choice), &write_word, sizeof(write_word),
+                        hipMemcpyHostToDevice);
     return RDF_OK;
 }
 
@@ -2312,6 +2318,7 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
     if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
     int best = 0, rc = RDF_OK;
     float best_ms = 0.f, heap_ms = 0.f;
+    const int before = forest_deep_choice(packed);      // (what a failing tune leaves in place)
     for (int c = 0; c < n_cand && rc == RDF_OK; ++c) {
         rc = set_deep_choice(packed, cand[c], false);
         float ms_min = 0.f;
@@ -2342,7 +2349,7 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != RDF_OK) {
-        set_deep_choice(packed, -1, false);
+        set_deep_choice(packed, before, false);
         return rc;
     }
     if (n_tried) *n_tried = n_cand;

@@ -1455,6 +1455,14 @@ def test_untuned_table_walks_heap_order_records_and_a_choice_travels_with_the_ta
     assert lib.rdf_forest_set_deep_from(g.packed(1.0).ptr, -1) == 0 and g.deep_from() is None
     assert _blocks_walked(rdf, gpu_runtime, g, depth, depth_np.shape) == 0
     assert rdf.DecisionForest.from_numpy(forest_np).adopt_packed(g.packed_bytes(1.0), 1.0) is not None
+    # a choice made for a table the process has not looked at yet (no info block read so far) goes into the table at the first look
+    k = rdf.DecisionForest.from_numpy(forest_np)
+    k.adopt_packed(g.packed_bytes(1.0), 1.0)                        # (carries "no choice")
+    assert lib.rdf_forest_set_deep_from(k.packed(1.0).ptr, 11) == 0
+    assert k.deep_from() == 11
+    again = rdf.DecisionForest.from_numpy(forest_np)
+    again.adopt_packed(k.packed_bytes(1.0), 1.0)
+    assert again.deep_from() == 11
     # memory that is not a packed table of this shape is refused at the first look
     junk = rdf.DecisionForest.from_numpy(forest_np)
     junk.adopt_packed(np.zeros_like(table), 1.0)
