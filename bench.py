@@ -383,6 +383,7 @@ def main():
     full_run = not multi and a.leg is None and not a.headline_only
 
     # ---- counters first: the child passes must run before this process touches the GPU ----
+    os.environ.setdefault("RDF_BENCH_RUN_ID", f"{os.getpid()}_{int(time.time())}")      # (inherited by the child passes: tune_forest)
     live = None
     if full_run and not a.no_counters:
         legs = ["headline", "cfg2"] + ([] if a.no_cfg5 else ["cfg5"]) + \
@@ -427,15 +428,40 @@ def main():
     # config 5's per-GPU shard: dense 1280x720 frames, T8/D22/C4 full forest (512 MB of hot records: beyond the 256-MB
     # Infinity Cache), one launch per step; two frames compared with the oracle
     # ================================================================================================================
-    def tune_forest(forest_obj, sample):
-        """Outside every timed region, like packing: which table serves the forest's deep levels (DecisionForest.tune)."""
+    def tune_forest(forest_obj, sample, key=None):
+        """Outside every timed region, like packing: which table serves the forest's deep levels (DecisionForest.tune).
+        `key`: ONE choice per forest and bench run -- the --pmc child passes of a leg and this process must walk the same
+        table, or a leg's counters describe another kernel than the one it timed (two tables within 2 % of each other, config 5's
+        "full" forest, tuned differently from process to process): the first process of the run that tunes a key leaves its
+        choice in the bench cache, the others take it."""
         if a.unpacked or a.no_tune:
             return None
+
+        def fixed(level, how):
+            assert lib.rdf_forest_set_deep_from(forest_obj.packed(1.0).ptr, int(level)) == 0
+            res = {"deep_from": int(level), "tried": None, "chosen_by": how}
+            forest_obj.__dict__.setdefault("_tuned", {})[1.0] = res     # (no auto-tune on top)
+            return res
         if a.deep_from is not None and a.headline_only:
-            assert lib.rdf_forest_set_deep_from(forest_obj.packed(1.0).ptr, int(a.deep_from)) == 0
-            forest_obj.__dict__.setdefault("_tuned", {})[1.0] = {"deep_from": int(a.deep_from), "tried": None}   # (no auto-tune on top)
-            return {"deep_from": int(a.deep_from), "tried": None}
-        return forest_obj.tune(sample)
+            return fixed(a.deep_from, "--deep-from")
+        run_id = os.environ.get("RDF_BENCH_RUN_ID")
+        path = os.path.join(CACHE, f"tune_{run_id}_{key}.json") if (run_id and key and not multi) else None
+        if path and os.path.exists(path):
+            try:
+                got = json.load(open(path))
+                return dict(fixed(got["deep_from"], "an earlier process of this bench run"), tried=got.get("tried"))
+            except Exception:       # noqa: BLE001 -- (a half-written file: tune here)
+                pass
+        res = forest_obj.tune(sample)
+        if path:
+            try:
+                os.makedirs(CACHE, exist_ok=True)
+                tmp = f"{path}.{os.getpid()}.tmp"
+                json.dump(res, open(tmp, "w"))
+                os.replace(tmp, path)
+            except OSError:
+                pass
+        return res
 
     def useful_lines(forest_obj, depth_arr):
         """The lines the timed launch needs from the L1 at the least (rdf_eval_forest_packed_stats: the same launch, same
@@ -474,7 +500,7 @@ def main():
         tune5 = None
         if not a.unpacked:
             forest5.packed(1.0)
-            tune5 = tune_forest(forest5, depth5[0:min(16, F5)])
+            tune5 = tune_forest(forest5, depth5[0:min(16, F5)], f"T{T5}_D{D5}_C{C5}_{topology}_{H5}x{W5}")
         for _ in range(warmup):
             ev.get_labels_forest(forest5, depth5, lab5)
         e5 = Events(rt, 2 * steps)
@@ -670,7 +696,7 @@ def main():
     tune = None
     if not a.unpacked:
         forest.packed(1.0)  # load-time repack, outside the timed region (like the reference's upload)
-        tune = tune_forest(forest, depth[0:min(32, F)])
+        tune = tune_forest(forest, depth[0:min(32, F)], f"T{T}_D{D}_C{C}_{a.topology}_{H}x{W}_F{F}")
 
     # ---- config 2 proper: ONE 848x480 frame per launch (dense frame 0) ----
     def leg_cfg2(n1, forest_obj=None):
@@ -1243,7 +1269,7 @@ def main():
             fb_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_balanced", lambda: synth.forest(T, D, C, "balanced")))
             fb = rdf.DecisionForest.from_numpy(fb_np)
             fb.packed(1.0)
-            tune_b = tune_forest(fb, depth[0:min(32, F)])
+            tune_b = tune_forest(fb, depth[0:min(32, F)], f"T{T}_D{D}_C{C}_balanced_{H}x{W}_F{F}")
             res = leg_cfg2(200, fb)
             lab_b = rdf.DeviceArray((F, H, W), np.uint16).fill(65535)
             for _ in range(2):

@@ -27,14 +27,19 @@ MI355X_MICROARCH.md for the peaks):
     on the data (tools/ubench_gather.hip, profiles/r05_ubench_gather.txt): 7.1-7.2 TB/s from a 146-MB and a 1.2-GB table, 6.5 TB/s
     from a 4-GB one, with the wave fetching its lines by LDS-DMA (16 or 8 waves per CU) as with one load per lane (24 waves):
     the `hbm` level carries `frac_of_gather_ceiling` beside its fraction of the 8 TB/s data-sheet peak.
-  * TA_TA_BUSY is NOT a utilisation of the L1's line rate once fills miss the L2: at that ceiling the counter reads 0.90 (LDS-DMA
-    gather, 0.20 line accesses per CU and cycle) and 0.98 (seven loads per lane, 0.63 per cycle) while the L1 serves 1.7 hits
-    per cycle -- a texture addresser whose requests wait for the fabric counts as busy (6.5-6.9 busy cycles per line that
-    misses the L2, at the ceiling).  `ta_busy_model` therefore adds, to the L1 level's cycles, a price per L2 miss of the
-    launch (TCC_MISS): 5.6 cycles for kernels whose misses are divergent 16-byte record loads, 3.5 for the deep-block kernels,
-    whose misses are whole lines fetched by the wave -- two constants FITTED on round 5's five legs (below the ceiling a miss
-    queues for less long than at it), which put the model within 8 % of the counter on all of them; round 4's model, without the
-    term, read 0.60 and 0.46 where the counter read 0.94 and 0.97.
+  * TA_TA_BUSY against the L1 level: the counter reads what the L1 level's calibrated cycles say (within 9 %, a little above) as long
+    as the fabric is far from its ceiling, and rises steeply as the launch approaches it -- the texture addresser's queues fill
+    up behind the misses.  Measured with the gather microbenchmark throttled by arithmetic between two fetches
+    (tools/calibrate_ta_busy.sh, profiles/r05_ta_busy_per_miss.txt): busy cycles per L2 miss BEYOND the L1 level's own cycles,
+    by the fraction of the gather ceiling the launch runs at -- the wave's cooperative LDS-DMA fetch 2.5 / 2.4 / 2.2 / 1.9 / 6.5
+    at 0.13 / 0.24 / 0.42 / 0.68 / 0.98: the curve the deep-block kernels are priced with, nothing fitted.  For the heap-order
+    kernels (divergent 16-byte record loads of which a few per cent miss the L2, at 0.06-0.28 of the ceiling) no microbenchmark
+    gives the price: the pure gather's every access is a fill, and there the L1 curve over-prices the access itself (its
+    residual is negative below 0.8 of the ceiling, 7.7 at 0.99).  Their 5.6 busy cycles per L2 miss are FITTED on the three
+    heap-order legs of profiles/r05_bench.json (the L1 level alone reads 3 / 8 / 14 % under the counter on them, in the order
+    of their miss counts).  `ta_busy_model` = the L1 level's cycles + TCC_MISS x that price: within 8 % of the counter on all
+    five legs -- round 4's model, the L1 level alone, read 0.60 and 0.46 where the counter read 0.94 and 0.97 (the seven-load
+    walk ran AT the texture addresser's limit; the cooperative walk runs at 0.71-0.84 of the fabric's).
   * VALU issue with more than one wave per SIMD: 2.35 cycles for the simple integer/fp32 instructions, 4.2 cycles for
     v_pk_*_f32, conversions, v_perm_b32 and the three-operand integer forms (tools/ubench_valu.hip); the kernel's mix is
     counted in its ISA (VALU_MIX below).
@@ -52,7 +57,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBS = 8000.0          # spec, MI355X_MICROARCH.md
 GATHER_CEILING_GBS = 7150.0    # random dependent 128-byte line gather, tables of 146 MB to 1.2 GB (profiles/r05_ubench_gather.txt)
-TA_BUSY_CYCLES_PER_L2_MISS = {"divergent": 5.6, "deep": 3.5}     # fitted on profiles/r05_bench.json's five legs (see the docstring)
+# profiles/r05_ta_busy_per_miss.txt: (fraction of the gather ceiling, TA busy cycles per L2 miss beyond the L1 level's cycles)
+TA_BUSY_CYCLES_PER_L2_MISS = {"deep": [(0.0, 2.5), (0.13, 2.5), (0.24, 2.39), (0.42, 2.18), (0.68, 1.94), (0.98, 6.46), (1.0, 6.46)],
+                              "divergent": [(0.0, 5.6), (0.80, 5.6), (0.99, 7.74), (1.0, 7.74)]}
+
+
+def ta_busy_cycles_per_l2_miss(kind, ceiling_fraction):
+    pts = TA_BUSY_CYCLES_PER_L2_MISS[kind]
+    u = min(max(ceiling_fraction, 0.0), 1.0)
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if u <= x1:
+            return y0 + (y1 - y0) * (u - x0) / (x1 - x0) if x1 > x0 else y1
+    return pts[-1][1]
 L2_L1_BYTES_PER_CLK_PER_CU = 64.0
 LINE = 128
 CUS = 256
@@ -210,12 +226,13 @@ def model(counters, kernel_ms, alg_bytes=None, cus=CUS, useful=None, kernel_name
                                                     if c.get("TA_TA_BUSY_sum") and c.get("_ns:TA_TA_BUSY_sum") else None),
                            "what": "L1 line accesses x the measured cycles per access at this launch's fill share "
                                    "(tools/ubench_l1_fill.hip) per CU against the kernel's cycles"}
-        if c.get("TCC_MISS_sum") is not None:
+        if c.get("TCC_MISS_sum") is not None and hbm is not None:
             kind = "deep" if is_deep_kernel(kernel_name) else "divergent"
-            busy = (ta_cycles + c["TCC_MISS_sum"] * TA_BUSY_CYCLES_PER_L2_MISS[kind] / cus) / cyc
-            levels["l1_ta"].update({"ta_busy_model": round(busy, 4), "ta_busy_model_what":
-                                    f"the level's cycles + {TA_BUSY_CYCLES_PER_L2_MISS[kind]} busy cycles per L2 miss ({kind} loads): what "
-                                    "TA_TA_BUSY should read -- the counter includes the time requests wait for the fabric"})
+            per_miss = ta_busy_cycles_per_l2_miss(kind, hbm / t / 1e9 / GATHER_CEILING_GBS)
+            busy = (ta_cycles + c["TCC_MISS_sum"] * per_miss / cus) / cyc
+            levels["l1_ta"].update({"ta_busy_model": round(busy, 4), "ta_busy_cycles_per_l2_miss": round(per_miss, 2), "ta_busy_model_what":
+                                    f"the level's cycles + {per_miss:.2f} busy cycles per L2 miss ({kind} loads at this launch's fraction of the "
+                                    "gather ceiling: profiles/r05_ta_busy_per_miss.txt): what TA_TA_BUSY should read"})
         if useful:
             lines = float(sum(useful.get(k, 0) for k in ("records", "leaf_rows", "far_probes", "blocks")))
             levels["l1_ta"].update({

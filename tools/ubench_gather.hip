@@ -5,8 +5,10 @@
 // 7.4-7.9 TB/s from a 151-MB one; 128-byte rows are not in its tables.
 //
 //   hipcc -O3 --offload-arch=gfx950 -o tools/bin/ubench_gather tools/ubench_gather.hip
-//   tools/bin/ubench_gather [steps per wave, default 400] [only: coop16 | coop8 | seven24 | one24, with the table in MB]
-//   (with `only`, ONE kernel shape runs on ONE table: what a rocprofv3 --pmc pass is pointed at, tools/calibrate_gather.sh)
+//   tools/bin/ubench_gather [steps per wave, default 400] [only: coop16 | coop8 | seven24 | one24] [table in MB] [think]
+//   (with `only`, ONE kernel shape runs on ONE table: what a rocprofv3 --pmc pass is pointed at, tools/calibrate_gather.sh;
+//    `think` = iterations of a dependent integer hash between two fetches of a wave: the request rate falls BELOW the ceiling, which is
+//    where the forest kernel runs -- what TA_TA_BUSY charges per L2 miss there calibrates tools/roofline.py's ta_busy_model)
 //
 // Table sizes: 146 MB (a T4/D20 forest's deep blocks: Infinity-Cache-sized), 1.2 GB (T8/D22's: HBM), 4 GB.
 // Fetch shapes, each with a dependent chain per wave (the next 64 line numbers are a hash of the data just read):
@@ -33,7 +35,7 @@ __device__ __forceinline__ uint32_t mix(uint32_t x)
 enum { kCoop = 0, kSeven = 1, kOne = 2 };
 
 template <int MODE>
-__global__ __launch_bounds__(512, MODE == kCoop ? 4 : 6) void k_gather(const char *table, uint32_t n_lines, int steps, uint32_t *out)
+__global__ __launch_bounds__(512, MODE == kCoop ? 4 : 6) void k_gather(const char *table, uint32_t n_lines, int steps, int think, uint32_t *out)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -76,12 +78,13 @@ __global__ __launch_bounds__(512, MODE == kCoop ? 4 : 6) void k_gather(const cha
         }
         acc ^= v.x ^ v.y ^ v.z ^ v.w;
         state = mix(state + (v.x & 1u) + 0x9e3779b9u);      // the next line depends on the data
+        for (int t = 0; t < think; ++t) state = mix(state);  // (a walk's arithmetic between two fetches)
     }
     if (acc == 0x12345679u) out[0] = acc;
 }
 
 template <int MODE>
-static double run(const char *table, uint32_t n_lines, int steps, int blocks_per_cu, int cus, uint32_t *out)
+static double run(const char *table, uint32_t n_lines, int steps, int blocks_per_cu, int cus, uint32_t *out, int think = 0)
 {
     const int lds = MODE == kCoop ? 8 * 8192 : (blocks_per_cu == 2 ? 80000 : 53000);   // (the LDS footprint sets the residency)
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds > 65536 ? lds : 65536));
@@ -91,12 +94,12 @@ static double run(const char *table, uint32_t n_lines, int steps, int blocks_per
     const int grid = cus * blocks_per_cu;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_gather<MODE>, dim3(grid), dim3(512), lds, 0, table, n_lines, steps / 4, out);      // warm-up
+    hipLaunchKernelGGL(k_gather<MODE>, dim3(grid), dim3(512), lds, 0, table, n_lines, steps / 4, think, out);      // warm-up
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_gather<MODE>, dim3(grid), dim3(512), lds, 0, table, n_lines, steps, out);
+        hipLaunchKernelGGL(k_gather<MODE>, dim3(grid), dim3(512), lds, 0, table, n_lines, steps, think, out);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -113,6 +116,7 @@ int main(int argc, char **argv)
     const int steps = argc > 1 ? atoi(argv[1]) : 400;
     const char *only = argc > 2 ? argv[2] : nullptr;
     const size_t only_mb = argc > 3 ? (size_t)atoi(argv[3]) : 1200;
+    const int think = argc > 4 ? atoi(argv[4]) : 0;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -126,11 +130,11 @@ int main(int argc, char **argv)
     if (only) {
         const uint32_t n_lines = (uint32_t)((only_mb << 20) >> 7);
         double r = 0;
-        if (!strcmp(only, "coop16")) r = run<kCoop>(table, n_lines, steps, 2, cus, out);
-        else if (!strcmp(only, "coop8")) r = run<kCoop>(table, n_lines, steps, 1, cus, out);
-        else if (!strcmp(only, "seven24")) r = run<kSeven>(table, n_lines, steps, 3, cus, out);
-        else if (!strcmp(only, "one24")) r = run<kOne>(table, n_lines, steps, 3, cus, out);
-        printf("table %5zu MB: %s %7.0f GB/s\n", only_mb, only, r);
+        if (!strcmp(only, "coop16")) r = run<kCoop>(table, n_lines, steps, 2, cus, out, think);
+        else if (!strcmp(only, "coop8")) r = run<kCoop>(table, n_lines, steps, 1, cus, out, think);
+        else if (!strcmp(only, "seven24")) r = run<kSeven>(table, n_lines, steps, 3, cus, out, think);
+        else if (!strcmp(only, "one24")) r = run<kOne>(table, n_lines, steps, 3, cus, out, think);
+        printf("table %5zu MB: %s think %d: %7.0f GB/s\n", only_mb, only, think, r);
         return 0;
     }
     for (int t = 0; t < 3; ++t) {
