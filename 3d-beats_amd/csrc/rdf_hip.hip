@@ -42,6 +42,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <tuple>
@@ -2026,7 +2027,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     const long long slab_bytes = coop ? (long long)(block / 64) * 8192 : 0;
 
     // ---- LDS plan: [depth tile: th*twp*2 B, at address 0][node table: T*2^K*16 B][queue mailbox 32 B][pixel list][slabs] ----
-    const long long budget = coop ? coop_lds_budget(block) : lds_budget(tw ? 256 : block);
+    // (whatever the budget knob says: a workgroup's tile, node table and slabs together fit a CU's 160 KB)
+    const long long budget = coop ? std::min<long long>(coop_lds_budget(block), 163840 - slab_bytes - 2048) : lds_budget(tw ? 256 : block);
     // filtered launches of the default geometry carry the pixel list in LDS (k_eval_forest<..., COMPACT>)
     const bool compact_launch = packed && !stats && filter_class != -1 && compaction;
     // Halo and the levels that must stay in LDS, by measurement (profiles/r02_sweep_*.txt).  256-thread workgroups (32.7 KB):

@@ -1185,6 +1185,31 @@ def test_deep_blocks_give_the_oracles_labels(rdf, evs, oracle, gpu_runtime, topo
         lib.rdf_set_deep_from(-1)
 
 
+def test_deep_blocks_under_every_lds_budget(rdf, evs, oracle, gpu_runtime):
+    """The LDS budget knob is for the depth tile and the node table; a launch that walks deep blocks adds 8 KB of slab per wave
+    on top.  Whatever the knob says (a whole CU's 160 KB, next to nothing), the workgroup fits a CU and the labels are the
+    oracle's -- round 5's first version let budget + slabs exceed 160 KB and the launch failed."""
+    lib = gpu_runtime.lib
+    forest = _deep_forest(rdf, "balanced", 4, 12, 4, first_tree=61)
+    depth = rdf.synth.frames(["dense", "live"], 1700, 120, 212)
+    want = np.full(depth.shape, 65535, np.uint16)
+    oracle.eval_forest(depth, forest, want)
+    try:
+        lib.rdf_set_deep_from(7)
+        for block in (256, 512):
+            for budget, halo in ((163840, 96), (163840, -1), (81920, 40), (4096, -1), (1, 0)):
+                lib.rdf_set_block_threads(block)
+                lib.rdf_set_lds_budget_bytes(budget)
+                lib.rdf_set_halo(halo)
+                got = _gpu_forest(rdf, evs["packed"], depth, forest, 65535)
+                assert np.array_equal(got, want), (block, budget, halo, int((got != want).sum()))
+    finally:
+        lib.rdf_set_deep_from(-1)
+        lib.rdf_set_block_threads(0)
+        lib.rdf_set_lds_budget_bytes(0)
+        lib.rdf_set_halo(-1)
+
+
 @pytest.mark.parametrize("r,use_filter,prefill", [(1, True, 65535), (2, False, 0), (2, True, 7), (3, False, 65535)])
 def test_deep_blocks_with_filter_reduce_and_prefill(rdf, evs, oracle, gpu_runtime, r, use_filter, prefill):
     lib = gpu_runtime.lib
