@@ -31,6 +31,40 @@ def shard_range(n_frames, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def replicate_forest(forest, src=0, group=None, packed_scales=()):
+    """The forest is REPLICATED on every GPU: one broadcast of rank `src`'s `forest_cu` (240 MiB for T4/D20, 1.9 GiB
+    for T8/D22) outside any timed region, instead of every rank reading the .npy.  Every rank passes a DecisionForest of the same
+    trees / depth / classes; the other ranks' contents are overwritten.  With `packed_scales`, rank `src`'s PACKED tables for those
+    scale factors go over as well -- deep-level choice included, it lives in the table -- so rank `src` packs and tunes once
+    (`forest.packed(s)`, `forest.tune(sample, scale_factor=s)`) and no other rank packs or tunes: every rank walks the same table.
+    Collective; returns `forest`."""
+    import torch.distributed as dist
+    from .decision_tree import _touch
+    rank = dist.get_rank(group)
+    dist.broadcast(forest.forest_cu.torch_bytes(), src=src, group=group)
+    if rank != src:
+        _touch(forest.forest_cu)                    # (written outside the array API: the packed-table cache must notice)
+    if packed_scales:
+        from .device import DeviceArray, get_runtime
+        lib = get_runtime().lib
+        nbytes = int(lib.rdf_forest_packed_bytes(int(forest.num_trees), int(forest.max_depth), int(forest.num_classes)))
+        for s_ in packed_scales:
+            s = float(np.float32(s_))
+            if nbytes == 0:
+                continue
+            if rank == src:
+                buf = forest.packed(s)
+            else:
+                hit = forest._packed.get(s)
+                buf = hit[1] if (hit is not None and hit[1].nbytes == nbytes) else DeviceArray((nbytes,), np.uint8)
+                forest._forget(buf)                 # whatever the library knew about this address
+            dist.broadcast(buf.torch_bytes(), src=src, group=group)
+            if rank != src:
+                forest._packed[s] = ((id(forest.forest_cu), forest.forest_cu.version), buf)
+                forest.__dict__.setdefault("_tuned", {}).pop(s, None)
+    return forest
+
+
 class ShardedForestEvaluator:
     """Evaluates this rank's shard and gathers every rank's label maps on `dst`.
 

@@ -74,6 +74,53 @@ def test_two_rank_gather_matches_oracle(n_chunks, tmp_path, oracle):
     assert (tmp_path / "ok").exists()
 
 
+def _replicate_worker(rank, world, port, tmpdir):
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    rdf = importlib.import_module("3d-beats_amd")
+    dmod = importlib.import_module("3d-beats_amd.distributed")
+    import fake_runtime
+    from oracle import rdf_oracle
+    rdf.set_runtime(fake_runtime.HostRuntime())
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames, h, w = 3, 36, 52
+        forest_np = rdf.synth.forest(3, 7, 4, "trained", 50)
+        # only rank 0 has the model; the others hold an empty forest of the same shape
+        forest = rdf.DecisionForest.from_numpy(forest_np) if rank == 0 else rdf.DecisionForest(3, 7, 4)
+        ev = rdf.DecisionTreeEvaluator()
+        mine = rdf.synth.mixed_batch(frames, first_idx=rank * frames, h=h, w=w)
+        depth, labels = rdf.to_device(mine), rdf.DeviceArray((frames, h, w), np.uint16).fill(65535)
+        if rank != 0:
+            ev.get_labels_forest(forest, depth, labels)          # (packs the EMPTY forest: the replica must not reuse that table)
+            labels.fill(65535)
+        assert dmod.replicate_forest(forest, src=0) is forest
+        assert np.array_equal(forest.forest_cu.get(), forest_np)
+        ev.get_labels_forest(forest, depth, labels)
+        want = np.full((frames, h, w), 65535, np.uint16)
+        rdf_oracle.eval_forest(mine, forest_np, want)
+        assert np.array_equal(labels.get(), want), f"rank {rank}"
+        packs = [c for c in rdf.get_runtime().lib.calls if c[0] == "rdf_forest_pack"]
+        assert len(packs) == (1 if rank == 0 else 2)            # rank 1 re-packed after the broadcast changed forest_cu
+        dist.barrier()
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forest_is_replicated_by_one_broadcast(tmp_path, oracle):
+    """the forest is replicated -- rank 0 holds the model, one broadcast of forest_cu gives it to the others, whose
+    packed-table cache notices the new contents; every rank's shard then gets the oracle's labels (two gloo ranks, host double)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_replicate_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
 def test_shard_range_partitions_the_batch(rdf):
     dmod = importlib.import_module("3d-beats_amd.distributed")
     for n, wsz in [(1024, 8), (10, 4), (3, 8), (256, 8)]:
@@ -212,6 +259,58 @@ def test_peer_copy_gather_across_two_devices(tmp_path, oracle):
         pytest.skip("needs two GPUs")
     mp.spawn(_p2p_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _replicate_gpu_worker(rank, world, port, tmpdir):
+    """Two processes on the one GPU: rank 0 packs AND tunes, one broadcast each gives rank 1 the forest and the tuned table."""
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    rdf = importlib.import_module("3d-beats_amd")
+    dmod = importlib.import_module("3d-beats_amd.distributed")
+    from oracle import rdf_oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames, h, w = 3, 120, 212
+        forest_np = rdf.synth.forest(4, 11, 4, "balanced", 70, calib=rdf.synth.calibration_frames(3, 120, 212))
+        lib = rdf.get_runtime().lib
+        if rank == 0:
+            forest = rdf.DecisionForest.from_numpy(forest_np)
+            assert lib.rdf_forest_set_deep_from(forest.packed(1.0).ptr, 6) == 0       # (stands in for forest.tune(sample))
+        else:
+            forest = rdf.DecisionForest(4, 11, 4)
+        dmod.replicate_forest(forest, src=0, packed_scales=(1.0,))
+        assert np.array_equal(forest.forest_cu.get(), forest_np)
+        table = forest._packed[1.0][1]
+        assert forest.packed(1.0) is table                                           # the cache takes the replica: no re-pack
+        assert forest.deep_from(1.0) == 6                                            # the choice came with the table
+        mine = rdf.synth.mixed_batch(frames, first_idx=rank * frames, h=h, w=w)
+        depth, labels = rdf.to_device(mine), rdf.DeviceArray((frames, h, w), np.uint16).fill(65535)
+        rdf.DecisionTreeEvaluator().get_labels_forest(forest, depth, labels)
+        want = np.full((frames, h, w), 65535, np.uint16)
+        rdf_oracle.eval_forest(mine, forest_np, want)
+        assert np.array_equal(labels.get(), want), f"rank {rank}"
+        st8 = rdf.DeviceArray((8,), np.uint64).fill(0)
+        assert lib.rdf_eval_forest_packed_stats(depth.ptr, frames, w, h, table.ptr, forest.forest_cu.ptr, 4, 11, 4, labels.ptr, 1, st8.ptr,
+                                                rdf.get_runtime().stream()) == 0
+        assert int(st8.get()[7]) > 0                                                 # ... and it is walked: deep blocks are fetched
+        dist.barrier()
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_packed_and_tuned_table_is_replicated_to_every_rank(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    mp.spawn(_replicate_gpu_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
 def _train_worker(rank, world, port, tmpdir):
