@@ -346,10 +346,12 @@ struct EvalArgsN {
 //                         (last-level table, deep blocks: their trailers)
 //   per tile              "take the next tile" (static first tile, then the per-XCD queues) -> "empty tile?" -> "stage depth" into
 //                         LDS at address 0 -> "compact" (COMPACT only)
-//   per pixel group       early-outs (tree_eval.cu:81-89), the pixel's reciprocal, then per CMAX classes and per GROUP trees:
+//   per pixel group       early-outs (tree_eval.cu:81-89; DEEP: a lane without a pixel stays in the loop with idle tree slots, `live`,
+//                         because the wave fetches its deep blocks together), the pixel's reciprocal, then per CMAX classes and per GROUP trees:
 //       the level loop    round-down mode; node fetch (LDS / packed table / reference records) -> probe coordinates (one fma per
 //                         coordinate, or the IEEE divide for flagged nodes) -> probes issued -> decisions (walk_step)
-//       then ONE of       "deep blocks" (DEEP: whole 128-byte blocks, tree after tree, leaf PDFs with the last block)
+//       then ONE of       "deep blocks" (DEEP: tree after tree, the WAVE fetches its lanes' 128-byte blocks with eight LDS-DMA loads into
+//                         its 8-KB slab, every lane reads the three records it takes; leaf PDFs with the last block)
 //                         "level D-1 from the last-level table" (node and both PDFs in one 64-byte record, tree after tree)
 //                         the general leaf fetch (PDF rows, in tree order)
 //       argmax (tree_eval.cu:7-21) and the label store
