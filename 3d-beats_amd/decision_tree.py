@@ -110,9 +110,10 @@ class DecisionForest:
         """The library keeps what it knows about a packed table per (device, address): told before the memory goes away, so that
         another table that later lands on the same address is read afresh (rdf_forest_forget)."""
         try:
-            lib = get_runtime().lib
-            if hasattr(lib, "rdf_forest_forget"):
-                lib.rdf_forest_forget(buf.ptr)
+            from . import device
+            rt = device._runtime            # (never CREATE a runtime for this: a finalizer may run at interpreter exit)
+            if rt is not None and hasattr(rt.lib, "rdf_forest_forget"):
+                rt.lib.rdf_forest_forget(buf.ptr)
         except Exception:       # noqa: BLE001 -- (interpreter shutdown, or a runtime that is already gone)
             pass
 
