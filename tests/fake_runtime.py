@@ -91,6 +91,12 @@ class _OracleLib:
         np.frombuffer(arr, dtype=np.uint16)[:] = value
         return 0
 
+    def rdf_convert_0s_to_maxuint(self, depth, n, stream):       # points_ops.cu:117-127
+        self.calls.append(("rdf_convert_0s_to_maxuint", int(n)))
+        a = np.frombuffer((ctypes.c_uint16 * int(n)).from_address(int(depth)), dtype=np.uint16)
+        a[a == 0] = 65535
+        return 0
+
     def rdf_stream_synchronize(self, stream):
         return 0
 

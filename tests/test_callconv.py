@@ -168,3 +168,70 @@ def test_dataset_conversions_are_the_references_own(rdf, tmp_path):
     assert colors.dtype.name == fx["colors_dtype"] and np.array_equal(colors, np.array(fx["colors"], dtype=np.uint8))
     back = ds.convert_colors_to_ids(np.array(fx["colors"], dtype=np.uint8)[1])
     assert back.dtype.name == fx["back_dtype"] and back.tolist() == fx["ids_back_from_colors_of_image_1"]
+
+
+def test_reference_app_constructor_runs_on_the_swapped_modules(rdf, host_runtime, tmp_path):
+    """The constructor section of the reference's live app (run_live_layered.py:6-14, 20-58), import lines and calls as they
+    stand there, on this package's modules (`install_reference_aliases`): the argument parser with py_nvcc_utils' two
+    options, config_compiler, LayeredDecisionForest.load with (y, x) dims, PointsOps, the GpuBuffers -- and the recorded
+    run() sequence afterwards.  (RealSense, the plane fit and the GL texture are out of scope: SURVEY section 2.)"""
+    import argparse
+    import sys
+    run = SCEN["layered_two_layers_run"]
+    for fn, shp in run["forest_shapes"].items():
+        np.save(tmp_path / fn, np.zeros(shp, np.float32))
+    cfg_path = tmp_path / "model_cfg.json"
+    cfg_path.write_text(json.dumps(run["config"]))
+    before = {n: sys.modules.get(n) for n in rdf._REFERENCE_MODULE_NAMES}
+    try:
+        assert rdf.install_reference_aliases() == list(rdf._REFERENCE_MODULE_NAMES)
+        ns = {}
+        exec("from decision_tree import *\n"                      # run_live_layered.py:6
+             "from cuda.points_ops import *\n"                    # :7
+             "import cuda.py_nvcc_utils as py_nvcc_utils\n"       # :10
+             "from engine.buffer import GpuBuffer\n"              # :14
+             "from cuda.mean_shift import *\n"                    # 3d_bz.py
+             "from util import MAX_UINT16\n", ns)
+        py_nvcc_utils = ns["py_nvcc_utils"]
+        parser = argparse.ArgumentParser(description='Train a classifier RDF for depth images')
+        parser.add_argument('-cfg', nargs='?', required=True, type=str)
+        parser.add_argument('--plane_num_iterations', nargs='?', required=False, type=int)
+        py_nvcc_utils.add_args(parser)                                                  # :23
+        args = parser.parse_args(["-cfg", str(cfg_path), "--fatbin_in", "fatbins/"])    # a command line written for the reference
+        py_nvcc_utils.config_compiler(args)                                             # :27
+        with pytest.raises(AssertionError):                                             # py_nvcc_utils.py:14
+            py_nvcc_utils.config_compiler(parser.parse_args(["-cfg", "x", "--fatbin_in", "a", "--fatbin_out", "b"]))
+        with pytest.raises(rdf.RdfError, match="prebuilt"):
+            py_nvcc_utils.get_module("tree_eval")
+        DIM_Y, DIM_X = run["depth_dims"]
+        LABELS_REDUCE = run["labels_reduce"]
+        layered_rdf = ns["LayeredDecisionForest"].load(args.cfg, (DIM_Y, DIM_X), LABELS_REDUCE)        # :54
+        points_ops = ns["PointsOps"]()                                                                  # :55
+        GpuBuffer = ns["GpuBuffer"]
+        depth_image = GpuBuffer((1, DIM_Y, DIM_X), np.uint16)                                           # :59
+        labels_image = GpuBuffer((1, DIM_Y // LABELS_REDUCE, DIM_X // LABELS_REDUCE), dtype=np.uint16)  # :62
+        assert ns["MAX_UINT16"] == 65535 and points_ops is not None
+        assert layered_rdf.__class__ is rdf.LayeredDecisionForest and GpuBuffer is rdf.GpuBuffer
+        # tick(): upload, 0 -> 65535, run (run_live_layered.py:117-126)
+        frame = np.full((1, DIM_Y, DIM_X), 1000, np.uint16)
+        frame[0, :4] = 0
+        depth_image.cu().set(frame)
+        points_ops.convert_0s_to_maxuint(np.int32(DIM_X * DIM_Y), depth_image.cu(), grid=((DIM_X * DIM_Y) // 1024 + 1, 1, 1), block=(1024, 1, 1))
+        assert (depth_image.cu().get()[0, :4] == 65535).all()
+        layered_rdf.fused = False
+        layered_rdf.eval.use_packed = False
+        lib = host_runtime.lib
+        del lib.trace[:]
+        layered_rdf.run(depth_image, labels_image, float(run["scale_factor"]))
+        roles = {rdf.device_ptr(b): f"layer{i}_labels" for i, b in enumerate(layered_rdf.label_images)}
+        roles.update({rdf.device_ptr(depth_image): "depth_image", rdf.device_ptr(labels_image): "labels_image",
+                      rdf.device_ptr(layered_rdf.labels_images_ptrs_cu): "label_pointer_table",
+                      rdf.device_ptr(layered_rdf.labels_conditions_cu): "conditions"})
+        roles.update({m.forest_cu.ptr: f"layer{i}_forest" for i, (m, _, _) in enumerate(layered_rdf.m)})
+        assert _my_events(lib.trace, roles) == _ref_events("layered_two_layers_run")
+    finally:
+        for n, m in before.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m

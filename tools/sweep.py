@@ -29,6 +29,7 @@ def main():
                     "the frame in 32x32 blocks (0: no filter)")
     ap.add_argument("--no-compaction", action="store_true")
     ap.add_argument("--check", type=int, default=0, help="compare the first N frames' labels with the oracle")
+    ap.add_argument("--no-compare", action="store_true", help="timing-only builds: the combos' labels need not agree")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=848)
     ap.add_argument("combos", nargs="*", default=["0:0", "256:32700", "512:54600"], help="0:0 = every default")
@@ -78,7 +79,7 @@ def main():
             else:
                 got = labels.get()
                 ref = got if ref is None else ref
-                assert np.array_equal(got, ref), c
+                assert a.no_compare or np.array_equal(got, ref), c
     if a.check:
         from oracle import rdf_oracle
         n = min(a.check, host.shape[0])
