@@ -38,6 +38,9 @@ SIGNATURES = {
                                         _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "rdf_eval_forest_packed_filled": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
                                                _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
+    "rdf_eval_forest_packed_split": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
+                                              _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
+                                              _c_int, ctypes.POINTER(_c_int)]),
     "rdf_eval_forest_stats": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                                        _c_void_p, _c_int, _c_void_p, _c_int, _c_float, _c_void_p, _c_void_p]),
     "rdf_mean_shift_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
@@ -105,6 +108,7 @@ SIGNATURES = {
     "rdf_set_force_exact": (None, [_c_int]),
     "rdf_set_last_level_table": (None, [_c_int]),
     "rdf_set_deep_from": (None, [_c_int]),
+    "rdf_set_fold": (None, [_c_int]),
     "rdf_event_create": (_c_int, [ctypes.POINTER(_c_void_p)]),
     "rdf_event_record": (_c_int, [_c_void_p, _c_void_p]),
     "rdf_event_synchronize": (_c_int, [_c_void_p]),
@@ -116,7 +120,7 @@ SIGNATURES = {
     "rdf_error_string": (ctypes.c_char_p, [_c_int]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

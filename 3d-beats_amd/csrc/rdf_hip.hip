@@ -41,6 +41,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -120,9 +121,15 @@ struct PackInfo {
     uint32_t deep_choice;   // which table serves the deep levels, chosen for THIS table (rdf_forest_set_deep_from / rdf_forest_tune):
                             // 0 = no choice made, 1 + level otherwise (1 = heap-order records).  It travels with the table: a process that
                             // maps or copies a tuned table (and every later evaluation in this one) finds the choice without tuning again
-    uint32_t pad[28];
+    uint32_t generation;    // (round 6) which packing this is: a non-zero number rdf_forest_pack draws per call, unlike any other this
+                            // process drew and, with 31 random bits, practically unlike another process's.  The host remembers it
+                            // with what else it knows about the table at this address and hands it to every launch; the KERNEL compares
+                            // it with the word in the table and raises the device's stale flag when they differ (a different table was
+                            // copied over a known address without rdf_forest_forget): the next call returns RDF_ERR_STALE
+    uint32_t n_trees, max_depth, n_classes;     // the shape the table was packed for
+    uint32_t pad[24];
 };
-constexpr uint32_t kPackMagic = 0x52444634u;   // "RDF4"
+constexpr uint32_t kPackMagic = 0x52444635u;   // "RDF5" (round 6: generation and shape words)
 // Last-level record, 64 bytes (forests of up to four classes): the hot record of a node of level D-1 and the PDFs of
 // its two leaves in ONE half cache line.  A walk that reaches level D-1 ends there (tree_eval.cu:95-128), so its last
 // node fetch and its leaf fetch are the same 128-byte line: fetched together they are one L1 fill instead of two
@@ -185,8 +192,16 @@ struct EvalArgs {
     unsigned long long *stats;
     int stats_wide;        // stats holds 8 counters (rdf_eval_forest_packed_stats), not 3
     unsigned int *sched;   // queue slot, or nullptr for static round-robin tiles
-    uint32_t n_tiles;      // n_img * tiles_x * tiles_y
-    uint32_t tiles_x;      // ceil(Wl / 64)
+    uint32_t n_tiles;      // n_img * (tiles_x * tiles_y + tiles_y_n)
+    uint32_t tiles_x;      // ceil(Wl / 64); with a folded last column: floor(Wl / 64)
+    // (round 6) The label map's last columns when Wl is not a multiple of 64 and at most 32 are left over (848 = 13 x 64 + 16):
+    // instead of a tile column whose waves run with 16 of 64 lanes, NARROW tiles of 64 / fold columns x fold x tile_rows rows in
+    // which a wave covers `fold` rows of 64 / fold pixels -- every lane has a pixel.  tiles_y_n of them per image, behind the
+    // image's ordinary tiles; their staged depth tile has its own shape.
+    uint32_t fold;         // 0: no narrow tiles; 2 or 4
+    uint32_t tiles_y_n;
+    int tw_n, th_n, twp_n;
+    uint32_t stage_tw8_n, stage_magic_n;
     uint32_t tiles_y;      // ceil(Hl / (waves per block * rows_per_wave))
     int rows_per_wave;     // 1..kMaxRowsPerWave
     uint32_t per_img_l;    // Wl*Hl
@@ -215,6 +230,17 @@ struct EvalArgs {
     int keep_if_no_leaf;   // single-tree semantics: no leaf reached -> pixel untouched
     int fill_untouched;    // fused pre-fill: write 65535 to every label pixel that is not evaluated
     float s;
+    // (round 6) the packed table's info block, the generation the host believes the table at this address has, and where a
+    // kernel that finds another one says so (pinned host memory, one word per device): see PackInfo.generation
+    const PackInfo *info;
+    uint32_t expect_gen;
+    unsigned int *stale_flag;
+    // (round 6) two launches that share ONE tile queue (rdf_eval_forest_packed_split: a main launch on a CU-masked stream and
+    // a helper launch that starts when the CUs left to another kernel are free again): q_static = tiles handed out
+    // statically (the main launch's grid; 0: this launch's own grid), q_blocks = workgroups of both launches together (the
+    // last of them puts the slot back to zero; 0: this launch's own), q_helper: this launch's workgroups have no static tile
+    uint32_t q_static, q_blocks;
+    int q_helper;
 };
 
 // A side continues iff floor(x) == -1  <=>  -1 <= x < 0   (NaN: false); anything else makes it a leaf.
@@ -380,6 +406,15 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
     const int lane = tid & 63;
     const int K = a.lds_levels;
     const uint32_t nodes_lds = (1u << K) - 1u;
+    // (round 6) the table's own words, not the host's memory of them: the scale its numerators were packed for (kFlagExact
+    // nodes recompute theirs with it) and the generation of the packing.  A table that is not the one the host remembers at
+    // this address raises the stale flag; the library then forgets what it knew and the next call says RDF_ERR_STALE.
+    float s_exact = a.s;
+    if (PACKED && a.info) {
+        s_exact = a.info->scale;
+        if (a.info->generation != a.expect_gen && a.stale_flag && blockIdx.x == 0 && tid == 0)
+            __hip_atomic_store(a.stale_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     constexpr uint32_t kWaves = BLOCK / 64;
     const int rows_per_wave = a.rows_per_wave;
     const uint32_t wave = (uint32_t)tid >> 6;
@@ -454,11 +489,12 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
         return (active && (!prev_active || prev != line)) ? 1u : 0u;
     };
     const char *depth_b = reinterpret_cast<const char *>(a.depth);
-    const int tw = a.tw, th = a.th, twp = a.twp;
     uint32_t static_tile = block_id;
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 7u;   // HW_REG_XCC_ID: the XCD this workgroup runs on
     uint32_t q_empty = 0u;                   // (thread 0) queues found empty so far
-    const uint32_t queued = a.n_tiles > n_blocks ? a.n_tiles - n_blocks : 0u;   // tiles the queues hand out (the first n_blocks are static)
+    const uint32_t q_static = a.q_static ? a.q_static : n_blocks;      // tiles handed out statically (split launches: the main launch's grid)
+    const uint32_t q_blocks = a.q_blocks ? a.q_blocks : n_blocks;      // workgroups that finish on this slot
+    const uint32_t queued = a.n_tiles > q_static ? a.n_tiles - q_static : 0u;   // tiles the queues hand out (the first q_static are static)
 
     for (uint32_t it = 0;; ++it) {
         // ---- take the next tile: 64 label columns x tile_rows label rows of one image ----
@@ -467,7 +503,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
             // A workgroup's FIRST tile is its own index: no atomic round trip in front of the first staging (2-3 us
             // of every launch), and a launch with no more tiles than workgroups -- one live frame -- touches no queue at
             // all: no pull, no failing pulls at the end, no finished-workgroup count.  The queues hand out the rest.
-            if (it == 0u) {
+            if (it == 0u && !a.q_helper) {
                 __syncthreads();
                 tile = block_id;     // (a permutation that hands each XCD a contiguous run of first tiles was tried: a
                                      // four-frame batch 0.24 -> 0.29 ms, larger batches unchanged)
@@ -475,22 +511,22 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
                 if (queued == 0u) break;             // (workgroup-uniform)
                 if (tid == 0) {
                     uint32_t t = a.n_tiles;      // nothing left anywhere
-                    if (n_blocks < kXcdQueuesFrom) {            // a small launch: one queue (head 0) over the rest
+                    if (q_static < kXcdQueuesFrom) {            // a small launch: one queue (head 0) over the rest
                         const uint32_t got = atomicAdd(a.sched, 1u);
-                        if (got < queued) t = n_blocks + got;
+                        if (got < queued) t = q_static + got;
                     } else {
                         // nothing guarantees that every XCD runs a workgroup of this launch (CU masks), so some workgroups
                         // -- eight consecutive ones in every 128, workgroups 0-7 always among them -- go round all queues
                         // (and every workgroup does when the queues hold several rounds of tiles: a few frames of uneven
                         // cost are uneven ranges, and the failing pulls at the end are a small share of such a launch)
-                        const uint32_t reach = (((block_id >> 3) & 15u) == 0u || queued >= 2u * n_blocks) ? 7u : kStealFrom;
+                        const uint32_t reach = (((block_id >> 3) & 15u) == 0u || queued >= 2u * q_static || a.q_helper) ? 7u : kStealFrom;
                         for (uint32_t k = 0; k <= reach; ++k) {
                             const uint32_t q = (xcc + k) & 7u;
                             if ((q_empty >> q) & 1u) continue;
                             const uint32_t lo = (uint32_t)(((unsigned long long)queued * q) >> 3);
                             const uint32_t hi = (uint32_t)(((unsigned long long)queued * (q + 1u)) >> 3);
                             const uint32_t got = lo < hi ? atomicAdd(a.sched + q * kSchedStride, 1u) : hi;
-                            if (lo < hi && got < hi - lo) { t = n_blocks + lo + got; break; }
+                            if (lo < hi && got < hi - lo) { t = q_static + lo + got; break; }
                             q_empty |= 1u << q;
                         }
                     }
@@ -505,17 +541,26 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
             static_tile += n_blocks;
         }
         if (tile >= a.n_tiles) break;
-        const uint32_t tiles_per_img = a.tiles_x * a.tiles_y;
+        const uint32_t tiles_wide = a.tiles_x * a.tiles_y;          // an image's ordinary tiles, then its narrow ones
+        const uint32_t tiles_per_img = tiles_wide + a.tiles_y_n;
         const uint32_t img = tile / tiles_per_img;
         const uint32_t trem = tile - img * tiles_per_img;
-        const uint32_t ty = trem / a.tiles_x;
-        const uint32_t tx = trem - ty * a.tiles_x;
-        const int lx = (int)(tx * 64u) + lane;
+        const bool narrow = trem >= tiles_wide;                     // (scalar)
+        const uint32_t ty = narrow ? trem - tiles_wide : trem / a.tiles_x;
+        const uint32_t tx = narrow ? a.tiles_x : trem - ty * a.tiles_x;
+        // where a wave's 64 lanes sit: one row of 64 pixels, or (narrow tiles) `fold` rows of 64 / fold
+        const uint32_t fold = narrow ? a.fold : 1u;
+        const uint32_t col_shift = narrow ? (a.fold == 4u ? 4u : 5u) : 6u;
+        const uint32_t lane_col = (uint32_t)lane & ((1u << col_shift) - 1u), lane_row = (uint32_t)lane >> col_shift;
+        const uint32_t x0 = tx * 64u, y0 = ty * tile_rows * fold;   // the tile's first label pixel
+        const int lx = (int)(x0 + lane_col);
         const uint32_t img_boff = (img * a.per_img_d) << 1;
         const uint32_t img_loff = img * a.per_img_l;
         // depth coordinates of the staged tile's first cell
-        const int tx0 = (int)(tx * 64u) * a.r - a.halo;
-        const int ty0 = (int)(ty * tile_rows) * a.r - a.halo;
+        const int tx0 = (int)x0 * a.r - a.halo;
+        const int ty0 = (int)y0 * a.r - a.halo;
+        const int tw = narrow ? a.tw_n : a.tw, th = narrow ? a.th_n : a.th, twp = narrow ? a.twp_n : a.twp;
+        const uint32_t stage_tw8 = narrow ? a.stage_tw8_n : a.stage_tw8, stage_magic = narrow ? a.stage_magic_n : a.stage_magic;
 
         const TileCtx pc = {depth_b + img_boff,
                             (uint32_t)tw * 2u, (uint32_t)th, (uint32_t)twp * 2u, (uint32_t)a.W * 2u, (uint32_t)a.H,
@@ -529,7 +574,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
             for (int sub = 0; sub < rows_per_wave; ++sub) {
                 const uint32_t trow = (uint32_t)sub * kWaves + wave;
                 if (trow >= tile_rows) break;
-                const int ly = (int)(ty * tile_rows + trow);
+                const int ly = (int)(y0 + trow * fold + lane_row);
                 if (ly < a.Hl && lx < a.Wl) {
                     const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
                     const uint32_t d = *reinterpret_cast<const uint16_t *>(
@@ -552,13 +597,13 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
         }
 
         // ---- stage depth [ty0, ty0+th) x [tx0, tx0+tw) into LDS; outside the image = 65535 ----
-        if (a.stage_tw8 > 0u) {
+        if (stage_tw8 > 0u) {
             // eight pixels per lane (one 128-bit load, one ds_write_b128): W, tx0 and the row pitch are multiples of 8, so
             // a vector lies inside or outside the image as a whole and every address is 16-byte aligned
-            const uint32_t total = (uint32_t)th * a.stage_tw8;
+            const uint32_t total = (uint32_t)th * stage_tw8;
             for (uint32_t i = (uint32_t)tid; i < total; i += BLOCK) {
-                const uint32_t row = __umulhi(i, a.stage_magic);
-                const uint32_t c = (i - row * a.stage_tw8) << 3;
+                const uint32_t row = __umulhi(i, stage_magic);
+                const uint32_t c = (i - row * stage_tw8) << 3;
                 const int gy = ty0 + (int)row, gx = tx0 + (int)c;
                 uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
                 if ((uint32_t)gy < (uint32_t)a.H && (uint32_t)gx < (uint32_t)a.W)
@@ -602,7 +647,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
             if (sub >= rows_per_wave || !compact) break;
             // rows of the workgroup's waves are interleaved: at any time they cover adjacent rows
             const uint32_t trow = (uint32_t)sub * kWaves + wave;
-            const int ly = (int)(ty * tile_rows + trow);
+            const int ly = (int)(y0 + trow * fold + lane_row);
             bool ok = trow < tile_rows && ly < a.Hl && lx < a.Wl;
             if (ok) {
                 const uint32_t i = img_loff + (uint32_t)ly * (uint32_t)a.Wl + (uint32_t)lx;
@@ -698,8 +743,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
                 }
                 entry = px_list[live ? slot : first];
             }
-            const int ly = (int)(ty * tile_rows + (entry >> 6));
-            const int px = (int)(tx * 64u + (entry & 63u));
+            // (entry = wave-row of the tile << 6 | lane)
+            const int ly = (int)(y0 + (entry >> 6) * fold + ((entry & 63u) >> col_shift));
+            const int px = (int)(x0 + (entry & ((1u << col_shift) - 1u)));
             if (!compact && (ly >= a.Hl || px >= a.Wl)) {
                 if (!DEEP) continue;
                 live = false;
@@ -815,13 +861,19 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
                                 for (int k = 0; k < GROUP; ++k) {
                                     if (n[k].flags & kFlagExact) {
                                         const int tk = min(kb + k, a.T - 1);
-                                        {
+                                        if (a.forest) {
                                             // (packed tables too: the numerators are recomputed from the caller's forest with the
-                                            // scale the table was packed for, a.s -- one multiply, as rdf_forest_pack did)
+                                            // scale the table was packed for -- read from the table's own info block -- one
+                                            // multiply, as rdf_forest_pack did)
                                             const float *p = a.forest +
                                                 ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
-                                            n[k].ax = a.s * p[0]; n[k].ay = a.s * p[1];
-                                            n[k].bx = a.s * p[2]; n[k].by = a.s * p[3];
+                                            n[k].ax = s_exact * p[0]; n[k].ay = s_exact * p[1];
+                                            n[k].bx = s_exact * p[2]; n[k].by = s_exact * p[3];
+                                        } else {
+                                            // a table with such nodes evaluated without the forest: the host checks its count and refuses
+                                            // (RDF_ERR_NULL_PTR), so this is a table the host does not know -- no fault, the stale flag
+                                            n[k].ax = n[k].ay = n[k].bx = n[k].by = 0.0f;
+                                            if (a.stale_flag) __hip_atomic_store(a.stale_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                         }
                                     }
                                 }
@@ -1184,7 +1236,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
     // workgroup has made its final, failing pull before it gets here) ----
     if (a.sched && queued != 0u && tid == 0) {
         const unsigned int done = atomicAdd(a.sched + 8 * kSchedStride, 1u);
-        if (done == n_blocks - 1u) {
+        if (done == q_blocks - 1u) {
             for (int q = 0; q < 9; ++q) atomicExch(a.sched + q * kSchedStride, 0u);
         }
     }
@@ -1205,7 +1257,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
 __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *packed16, PackInfo *info,
                                               float *packed_pdf, LastLevelRec *last_level, unsigned int *last_level_unusable,
                                               uint4 *deep, int n_trees, int C, int cpad,
-                                              size_t total_slots, int D, int E, float s, int force_exact)
+                                              size_t total_slots, int D, int E, float s, int force_exact, uint32_t generation)
 {
     // slot = tree * 2^D + h, h = 1-based heap index (slot h == 0 of each tree is unused and zeroed)
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1215,7 +1267,10 @@ __global__ __launch_bounds__(256) void k_pack(const float *forest, NodeRec16 *pa
         NodeRec16 z16 = {{0u, 0u, 0u, 0u}};
         packed16[slot] = z16;
         for (int c = 0; c < 2 * cpad; ++c) packed_pdf[slot * 2 * (size_t)cpad + c] = 0.f;
-        if (tree == 0) { info->scale = s; info->magic = kPackMagic; }
+        if (tree == 0) {
+            info->scale = s; info->magic = kPackMagic; info->generation = generation;
+            info->n_trees = (uint32_t)n_trees; info->max_depth = (uint32_t)D; info->n_classes = (uint32_t)C;
+        }
         if (deep && tree == 0) {     // the all-zero line behind the blocks
             uint4 *z = deep + (deep_total_lines(n_trees, D, cpad) << 3);
             for (int i = 0; i < 8; ++i) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1607,6 +1662,16 @@ bool tile_at_lds_zero(const void *kernel)
     return hipFuncGetAttributes(&fa, kernel) == hipSuccess && fa.sharedSizeBytes == 0;
 }
 
+// A launch in two parts that share one tile queue (rdf_eval_forest_packed_split): the entry point leaves its wishes here for
+// the launch_one at the end of its eval_common (thread-local: the plan in between is the ordinary one).
+struct SplitSpec {
+    hipStream_t helper_stream;
+    int helper_cus;     // compute units the helper launch may count on (its grid: this many times the workgroups a CU holds)
+    int tag;            // which of the stream's split queue slots (callers alternate it from step to step)
+    int launched;       // (out) workgroups of the helper launch; 0: the launch was not split
+};
+thread_local SplitSpec *tl_split = nullptr;
+
 template <int BLOCK, bool PACKED, int CMAX, bool STATS, int GROUP, bool COMPACT, bool DEEP = false>
 int launch_one(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
 {
@@ -1641,6 +1706,24 @@ int launch_one(const EvalArgs &a, int lds_bytes, int cus, hipStream_t st)
     if (grid < 1) grid = 1;
     EvalArgsN<1> ka;
     ka.l[0] = a;
+    if (tl_split && a.sched && sched_mode() == 1 && (long long)a.n_tiles > grid) {
+        // main launch: `grid` workgroups with a static first tile each; helper launch: workgroups that only pull from the
+        // queues.  Either order of arrival is correct: the queues hand out the tiles beyond `grid` whoever asks, and the
+        // workgroup that finishes last -- of both launches together -- puts the slot back to zero.
+        long long hgrid = (long long)tl_split->helper_cus * per_cu;
+        if (hgrid > (long long)a.n_tiles - grid) hgrid = (long long)a.n_tiles - grid;
+        if (hgrid >= 1) {
+            ka.l[0].q_static = (uint32_t)grid;
+            ka.l[0].q_blocks = (uint32_t)(grid + hgrid);
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, ka);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return (int)e;
+            ka.l[0].q_helper = 1;
+            hipLaunchKernelGGL(kern, dim3((unsigned)hgrid), dim3(BLOCK), lds_bytes, tl_split->helper_stream, ka);
+            tl_split->launched = (int)hgrid;
+            return (int)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, st, ka);
     return (int)hipGetLastError();
 }
@@ -1769,8 +1852,24 @@ struct PackedState {
     int exact_nodes = -1;      // -1: not read back yet
     float scale = 1.0f;
     const void *info_dev = nullptr;     // the table's info block in device memory, once known (the choice is written through to it)
+    uint32_t generation = 0;   // PackInfo.generation as read back: every launch carries it, the kernel compares
+    // the deep blocks' trailer (k_pack): 1 + the deepest level that holds a kFlagExact node, and the nodes of level D-1 that are
+    // not plain two-leaf nodes -- the blocks serve a launch only from a root level >= deep_min_root and only if deep_bad_last == 0
+    uint32_t deep_min_root = 0, deep_bad_last = 0;
 };
 std::map<std::pair<int, const void *>, PackedState> g_packed;
+
+// The device a table lives on: the (device, address) keys must not depend on which device happens to be current when a
+// finalizer or another thread calls rdf_forest_forget / rdf_forest_set_deep_from (falls back to the current device).
+int device_of(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice) return at.device;
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
 
 int forest_deep_choice(const void *packed)
 {
@@ -1781,10 +1880,70 @@ int forest_deep_choice(const void *packed)
     return it == g_packed.end() ? -1 : it->second.deep_from;
 }
 
+// ---- the stale flag: one word of pinned host memory per device that kernels can write (PackInfo.generation) ----
+struct StaleFlag {
+    volatile unsigned int *host = nullptr;
+    unsigned int *dev = nullptr;
+};
+std::map<int, StaleFlag> g_stale;       // (under g_sched_mu)
+// allocated when a device's first packed table is looked at (never during a stream capture: packed_info refuses those)
+StaleFlag stale_flag_for(int dev, bool create)
+{
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    auto it = g_stale.find(dev);
+    if (it != g_stale.end()) return it->second;
+    StaleFlag f;
+    if (!create) return f;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && h) {
+        memset(h, 0, 64);
+        if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+            f.host = reinterpret_cast<volatile unsigned int *>(h);
+            f.dev = reinterpret_cast<unsigned int *>(d);
+        } else {
+            (void)hipHostFree(h);
+        }
+    }
+    (void)hipGetLastError();
+    g_stale.emplace(dev, f);            // (a failed allocation is remembered too: launches then carry no flag)
+    return f;
+}
+// true once after a kernel on this device found a table that was not the one the host remembered: everything the host knew
+// about this device's tables is dropped (the flag does not say which), so the next evaluation of each reads its info block again
+bool stale_flag_raised(int dev)
+{
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    auto it = g_stale.find(dev);
+    if (it == g_stale.end() || !it->second.host || *it->second.host == 0u) return false;
+    *it->second.host = 0u;
+    for (auto p = g_packed.begin(); p != g_packed.end();) p = p->first.first == dev ? g_packed.erase(p) : std::next(p);
+    return true;
+}
+
+std::atomic<uint32_t> g_generation{0};
+uint32_t next_generation()      // non-zero, unlike any other this process drew; 31 random bits set it apart from other processes
+{
+    uint32_t seed = g_generation.load(std::memory_order_relaxed);
+    if (seed == 0u) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        uint32_t s = (uint32_t)ts.tv_nsec * 2654435761u ^ (uint32_t)ts.tv_sec * 40503u ^ ((uint32_t)getpid() << 16);
+        s = (s | 1u) & 0x7FFFFFFFu;
+        uint32_t expect = 0u;
+        g_generation.compare_exchange_strong(expect, s);
+    }
+    uint32_t g = g_generation.fetch_add(2u, std::memory_order_relaxed) + 2u;   // (stays odd: never zero)
+    return g;
+}
+
+static size_t info_offset(int n_trees, int max_depth, int n_classes);
+static size_t deep_offset(int n_trees, int max_depth, int n_classes);
+static size_t deep_bytes(int n_trees, int max_depth, int n_classes);
+
 // The table's info block as the host knows it; read back from the device once (a synchronous 128-byte copy behind whatever the
 // stream holds: rdf_forest_pack does it, and so does the first evaluation of a table this process did not pack at this
-// address).  Returns 0 and fills `out`, or an error code.
-int packed_info(const void *packed, const void *info_dev, void *stream, PackedState *out)
+// address), together with the deep blocks' trailer.  Returns 0 and fills `out`, or an error code.
+int packed_info(const void *packed, int n_trees, int max_depth, int n_classes, void *stream, PackedState *out)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
@@ -1794,26 +1953,41 @@ int packed_info(const void *packed, const void *info_dev, void *stream, PackedSt
         const auto it = g_packed.find(key);
         if (it != g_packed.end() && it->second.exact_nodes >= 0) { *out = it->second; return RDF_OK; }
     }
+    const void *info_dev = reinterpret_cast<const char *>(packed) + info_offset(n_trees, max_depth, n_classes);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
         return RDF_ERR_CAPTURE;     // a table's first evaluation cannot be recorded into a graph: evaluate it once before capturing
     PackInfo host;
+    uint32_t trailer[2] = {0u, 0u};
     hipError_t e = hipMemcpyAsync(&host, info_dev, sizeof(host), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream));
+    const size_t db = deep_bytes(n_trees, max_depth, n_classes);
+    if (e == hipSuccess && db != 0)
+        e = hipMemcpyAsync(trailer, reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes) + db - 128, sizeof(trailer),
+                           hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return (int)e;
-    if (host.magic != kPackMagic) return RDF_ERR_BAD_ARG;       // not a table this library's rdf_forest_pack wrote (or another shape)
-    std::lock_guard<std::mutex> lock(g_sched_mu);
-    PackedState &st = g_packed[key];
-    st.exact_nodes = (int)(host.exact_nodes > 0x7FFFFFFFu ? 0x7FFFFFFFu : host.exact_nodes);
-    st.scale = host.scale;
-    st.info_dev = info_dev;
-    // the choice the table carries (made by whoever tuned it, in this process or another), unless this process made one since
-    // (rdf_forest_set_deep_from on a table it had not looked at yet): that one goes into the table now
+    // not a table this library version's rdf_forest_pack wrote, or one of another shape
+    if (host.magic != kPackMagic || host.generation == 0u || host.n_trees != (uint32_t)n_trees || host.max_depth != (uint32_t)max_depth ||
+        host.n_classes != (uint32_t)n_classes)
+        return RDF_ERR_BAD_ARG;
+    (void)stale_flag_for(dev, true);
     uint32_t write_word = 0u;
-    if (st.deep_from < 0 && host.deep_choice != 0u && host.deep_choice <= 31u) st.deep_from = (int)host.deep_choice - 1;
-    else if (st.deep_from >= 0 && host.deep_choice != (uint32_t)st.deep_from + 1u) write_word = (uint32_t)(st.deep_from > 30 ? 30 : st.deep_from) + 1u;
-    *out = st;
-    if (write_word != 0u)
+    {
+        std::lock_guard<std::mutex> lock(g_sched_mu);
+        PackedState &st = g_packed[key];
+        st.exact_nodes = (int)(host.exact_nodes > 0x7FFFFFFFu ? 0x7FFFFFFFu : host.exact_nodes);
+        st.scale = host.scale;
+        st.info_dev = info_dev;
+        st.generation = host.generation;
+        st.deep_min_root = trailer[0];
+        st.deep_bad_last = trailer[1];
+        // the choice the table carries (made by whoever tuned it, in this process or another), unless this process made one since
+        // (rdf_forest_set_deep_from on a table it had not looked at yet): that one goes into the table now
+        if (st.deep_from < 0 && host.deep_choice != 0u && host.deep_choice <= 31u) st.deep_from = (int)host.deep_choice - 1;
+        else if (st.deep_from >= 0 && host.deep_choice != (uint32_t)st.deep_from + 1u) write_word = (uint32_t)(st.deep_from > 30 ? 30 : st.deep_from) + 1u;
+        *out = st;
+    }
+    if (write_word != 0u)       // (outside the lock: a synchronous copy must not hold up other threads' launches)
         (void)hipMemcpy(reinterpret_cast<char *>(const_cast<void *>(info_dev)) + offsetof(PackInfo, deep_choice), &write_word, sizeof(write_word),
                         hipMemcpyHostToDevice);
     return RDF_OK;
@@ -1824,8 +1998,8 @@ int packed_info(const void *packed, const void *info_dev, void *stream, PackedSt
 int set_deep_choice(const void *packed, int level, bool write_through)
 {
     if (!packed) return RDF_ERR_NULL_PTR;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    const int dev = device_of(packed);
+    if (dev < 0) return RDF_ERR_NO_DEVICE;
     const void *info_dev = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_sched_mu);
@@ -1890,6 +2064,7 @@ static size_t info_offset(int n_trees, int max_depth, int n_classes)
 }
 
 
+Knob g_fold{-1};                                // -1/1: narrow tiles for a label map's last <= 32 columns (EvalArgs.fold); 0: never
 Knob g_halo{-1};
 Knob g_lds_levels{-1};
 Knob g_tree_waves{-1};
@@ -1927,6 +2102,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     if (rc != 0) return rc;
 
     EvalArgs a;
+    PackedState ps;
     memset(&a, 0, sizeof(a));
     a.depth = depth; a.forest = forest; a.filter = filter; a.labels = labels_out;
     a.stats = stats;
@@ -1945,14 +2121,31 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         a.packed_pdf = reinterpret_cast<const float *>(a.packed16 + slots);
         a.cpad = (n_classes + 3) & ~3;
         // nodes that need the exact numerators read them from the caller's forest, with the scale the table was packed for
-        PackedState ps;
-        rc = packed_info(packed, reinterpret_cast<const char *>(packed) + info_offset(n_trees, max_depth, n_classes), stream, &ps);
+        // a kernel of an earlier call found a table that was not the one the host remembered at its address (a copy over a
+        // known address without rdf_forest_forget): what the host knew is gone, this call says so, the next one reads afresh
+        if (stale_flag_raised(di.dev)) return RDF_ERR_STALE;
+        rc = packed_info(packed, n_trees, max_depth, n_classes, stream, &ps);
         if (rc != RDF_OK) return rc;
         if (ps.exact_nodes > 0 && !forest) return RDF_ERR_NULL_PTR;
         a.s = ps.scale;
+        a.info = reinterpret_cast<const PackInfo *>(ps.info_dev);
+        a.expect_gen = ps.generation;
+        a.stale_flag = stale_flag_for(di.dev, false).dev;
     }
 
     a.tiles_x = ((uint32_t)a.Wl + 63u) / 64u;
+    // (round 6) a label map whose width leaves at most 32 columns beyond a multiple of 64 (848 = 13 x 64 + 16: every frame of the
+    // metric) gets NARROW tiles for those columns -- a wave covers 2 rows x 32 or 4 rows x 16 pixels there -- instead of a tile
+    // column whose waves run three quarters empty: 5.4 % fewer wave-rows on an 848-wide frame (EvalArgs.fold)
+    const int fold_knob = g_fold;
+    const int want_fold = fold_knob >= 0 ? fold_knob : env_int("RDF_FOLD", 1);
+    {
+        const int w_rem = a.Wl % 64;
+        if (want_fold && a.Wl > 64 && w_rem != 0 && w_rem <= 32) {
+            a.fold = w_rem <= 16 ? 4u : 2u;
+            a.tiles_x = (uint32_t)a.Wl / 64u;
+        }
+    }
     // Throughput shape: the launch fills the chip with four-row waves.  Small launches (a single live frame) take fewer
     // rows per wave so that every CU still gets several waves.
     const long long waves_wanted = 24ll * di.cus;
@@ -1984,6 +2177,14 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         if (deep_from_wanted < 0) deep_from_wanted = kUntunedDeepFrom;             // else the heap-order records
         const char *dp = reinterpret_cast<const char *>(packed) + deep_offset(n_trees, max_depth, n_classes);
         if ((reinterpret_cast<uintptr_t>(dp) & 127u) != 0) deep_from_wanted = 0;
+        // what the kernel would find in the blocks' trailer, known to the host since the table was first seen: blocks that cannot
+        // serve the forest (a level D-1 node that is not a plain two-leaf node; exact nodes down to the last block) are not planned
+        // for at all -- the launch takes the ordinary geometry instead of the deep one with heap-order records in it
+        if (deep_from_wanted > 0) {
+            const int R0 = max_depth - deep_last_levels((n_classes + 3) & ~3);
+            if (ps.deep_bad_last != 0u || (int)ps.deep_min_root > R0) deep_from_wanted = 0;
+            else if (deep_from_wanted < (int)ps.deep_min_root) deep_from_wanted = (int)ps.deep_min_root;      // (rounded up to a root below)
+        }
     }
     const int rpw_knob = g_rows_per_wave;
     int rpw = rpw_knob > 0 ? rpw_knob : env_int("RDF_ROWS_PER_WAVE", 0);
@@ -2017,7 +2218,8 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
     a.rows_per_wave = rpw;
     const uint32_t tile_rows = tw ? (uint32_t)(8 / n_trees) : (uint32_t)(block / 64) * (uint32_t)rpw;
     a.tiles_y = ((uint32_t)a.Hl + tile_rows - 1u) / tile_rows;
-    const long long n_tiles = (long long)n_img * a.tiles_x * a.tiles_y;
+    a.tiles_y_n = a.fold ? ((uint32_t)a.Hl + tile_rows * a.fold - 1u) / (tile_rows * a.fold) : 0u;
+    const long long n_tiles = (long long)n_img * ((long long)a.tiles_x * a.tiles_y + a.tiles_y_n);
     if (n_tiles >= (1ll << 31)) return RDF_ERR_TOO_LARGE;
     a.n_tiles = (uint32_t)n_tiles;
 
@@ -2078,13 +2280,28 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         if (vec) tw = (tw + 7) & ~7ll;                      // a few more columns than the probes' reach: harmless
         long long twp = vec ? tw : (tw + 1) & ~1ll;
         if (vec && (twp * 2) % 512 == 0) twp += 8;          // not a whole number of LDS bank sweeps per row
-        const long long bytes = (th * twp * 2 + 15) & ~15ll;
+        long long bytes = (th * twp * 2 + 15) & ~15ll;
+        // (narrow tiles: 64 / fold columns x fold x tile_rows rows of centres, the same halo; the allocation holds either shape)
+        long long tw_n = 0, th_n = 0, twp_n = 0;
+        if (a.fold) {
+            tw_n = (64ll / a.fold - 1) * r + 1 + 2ll * h;
+            th_n = ((long long)tile_rows * a.fold - 1) * r + 1 + 2ll * h;
+            if (vec) tw_n = (tw_n + 7) & ~7ll;
+            twp_n = vec ? tw_n : (tw_n + 1) & ~1ll;
+            if (vec && (twp_n * 2) % 512 == 0) twp_n += 8;
+            bytes = std::max(bytes, (th_n * twp_n * 2 + 15) & ~15ll);
+        }
         if (bytes <= tile_budget) {
             tile_bytes = bytes;
             a.halo = h; a.tw = (int)tw; a.th = (int)th; a.twp = (int)twp;
+            a.tw_n = (int)tw_n; a.th_n = (int)th_n; a.twp_n = (int)twp_n;
             if (vec) {
                 a.stage_tw8 = (uint32_t)(tw >> 3);
                 a.stage_magic = (uint32_t)((1ull << 32) / a.stage_tw8) + 1u;
+                if (a.fold) {
+                    a.stage_tw8_n = (uint32_t)(tw_n >> 3);
+                    a.stage_magic_n = (uint32_t)((1ull << 32) / a.stage_tw8_n) + 1u;
+                }
             }
             break;
         }
@@ -2133,7 +2350,7 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         return RDF_OK;
     }
 
-    a.sched = sched_slot(stream);
+    a.sched = tl_split ? sched_slot(stream, 16 + (tl_split->tag & 3)) : sched_slot(stream);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int cus = usable_cus(st, di.cus);   // a CU-masked stream holds fewer persistent workgroups
@@ -2229,8 +2446,8 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
         if (e != hipSuccess) return (int)e;
     }
     {   // a re-packed table is another forest: what the host knew of the old one goes
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) {
+        const int dev = device_of(packed);
+        if (dev >= 0) {
             std::lock_guard<std::mutex> lock(g_sched_mu);
             g_packed.erase(std::make_pair(dev, (const void *)packed));
         }
@@ -2247,13 +2464,13 @@ int rdf_forest_pack(const float *forest, int n_trees, int max_depth, int n_class
                        forest, reinterpret_cast<NodeRec16 *>(packed), info,
                        reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + total * sizeof(NodeRec16)),
                        last_level, unusable, deep, n_trees, n_classes, classes_padded(n_classes), total,
-                       max_depth, 7 + 2 * n_classes, scale_factor, (int)g_force_exact);
+                       max_depth, 7 + 2 * n_classes, scale_factor, (int)g_force_exact, next_generation());
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return (int)le;
     // what the kernel found (nodes that need the exact numerators) comes back now: packing is load time, and evaluations -- also
     // those recorded into a hipGraph -- then never have to ask the device
     PackedState ps;
-    return packed_info(packed, info, stream, &ps);
+    return packed_info(packed, n_trees, max_depth, n_classes, stream, &ps);
 }
 
 int rdf_eval_forest_packed(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
@@ -2282,7 +2499,7 @@ int rdf_forest_info(const void *packed, int n_trees, int max_depth, int n_classe
     if (!packed) return RDF_ERR_NULL_PTR;
     if (n_trees < 1 || max_depth < 1 || max_depth > 27 || n_classes < 0) return RDF_ERR_BAD_ARG;
     PackedState ps;
-    const int rc = packed_info(packed, reinterpret_cast<const char *>(packed) + info_offset(n_trees, max_depth, n_classes), stream, &ps);
+    const int rc = packed_info(packed, n_trees, max_depth, n_classes, stream, &ps);
     if (rc != RDF_OK) return rc;
     if (deep_from) *deep_from = ps.deep_from;
     if (exact_nodes) *exact_nodes = ps.exact_nodes;
@@ -2293,8 +2510,9 @@ int rdf_forest_info(const void *packed, int n_trees, int max_depth, int n_classe
 int rdf_forest_forget(const void *packed)
 {
     if (!packed) return RDF_ERR_NULL_PTR;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return RDF_ERR_NO_DEVICE;
+    // (the table's own device, not the current one: finalizers call this from wherever they run)
+    const int dev = device_of(packed);
+    if (dev < 0) return RDF_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_sched_mu);
     g_packed.erase(std::make_pair(dev, packed));
     return RDF_OK;
@@ -2322,6 +2540,13 @@ int rdf_forest_tune(const uint16_t *depth, int n_img, int dim_x, int dim_y, cons
     if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
     int best = 0, rc = RDF_OK;
     float best_ms = 0.f, heap_ms = 0.f;
+    {   // the table is looked at BEFORE the first candidate goes into the host's map: packed_info writes a choice it finds there
+        // into a table it sees for the first time (rdf_forest_set_deep_from before the first evaluation), and a trial candidate
+        // is not a choice -- a failing tune must leave the table, its copies and other processes without one
+        PackedState seen;
+        rc = packed_info(packed, n_trees, max_depth, n_classes, stream, &seen);
+        if (rc != RDF_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    }
     const int before = forest_deep_choice(packed);      // (what a failing tune leaves in place)
     for (int c = 0; c < n_cand && rc == RDF_OK; ++c) {
         rc = set_deep_choice(packed, cand[c], false);
@@ -2385,6 +2610,32 @@ int rdf_eval_forest_packed_filled(const uint16_t *depth, int n_img, int dim_x, i
     }
     return eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees, max_depth, n_classes, filter, filter_class,
                        labels_out, labels_reduce, 1.0f, 0, nullptr, stream, /*fill_untouched=*/1);
+}
+
+int rdf_eval_forest_packed_split(const uint16_t *depth, int n_img, int dim_x, int dim_y, const void *packed,
+                                 const float *forest, int n_trees, int max_depth, int n_classes,
+                                 const uint16_t *filter, int filter_class, uint16_t *labels_out,
+                                 int labels_reduce, int fill_untouched, void *stream, void *helper_stream, int helper_cus,
+                                 int queue_tag, int *helper_workgroups)
+{
+    if (helper_workgroups) *helper_workgroups = 0;
+    if (!packed) return RDF_ERR_NULL_PTR;
+    if (max_depth > 27 || helper_cus < 0) return RDF_ERR_BAD_ARG;
+    if (helper_cus == 0 || helper_stream == stream)
+        return eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees, max_depth, n_classes, filter, filter_class,
+                           labels_out, labels_reduce, 1.0f, 0, nullptr, stream, fill_untouched ? 1 : 0);
+    for (void *s : {stream, helper_stream}) {       // (a graph replays on one stream; two launches on two streams are not recorded)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(reinterpret_cast<hipStream_t>(s), &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
+            return RDF_ERR_CAPTURE;
+    }
+    SplitSpec spec = {reinterpret_cast<hipStream_t>(helper_stream), helper_cus, queue_tag, 0};
+    tl_split = &spec;
+    const int rc = eval_common(depth, n_img, dim_x, dim_y, packed, forest, n_trees, max_depth, n_classes, filter, filter_class,
+                               labels_out, labels_reduce, 1.0f, 0, nullptr, stream, fill_untouched ? 1 : 0);
+    tl_split = nullptr;
+    if (helper_workgroups) *helper_workgroups = spec.launched;
+    return rc;
 }
 
 int rdf_composite(const uint16_t *const *label_images, int n_images, int dim_x, int dim_y, const int32_t *cond,
@@ -2589,6 +2840,7 @@ void rdf_set_rows_per_wave(int rows) { g_rows_per_wave = rows; }
 void rdf_set_force_exact(int on) { g_force_exact = on; }
 void rdf_set_last_level_table(int on) { g_last_level_table = on; }
 void rdf_set_deep_from(int level) { g_deep_from = level; }
+void rdf_set_fold(int on) { g_fold = on; }
 
 int rdf_stream_create_with_reserved_cus(void **stream, int n_reserved)
 {
@@ -2769,6 +3021,7 @@ const char *rdf_error_string(int code)
     case RDF_ERR_TOO_LARGE: return "rdf: call addresses >= 2^31 pixels (or a frame is 2^23 pixels wide / 2^24 high or more), split the batch";
     case RDF_ERR_NO_DEVICE: return "rdf: no usable HIP device";
     case RDF_ERR_CAPTURE: return "rdf: the stream is being captured into a hipGraph and this call needs a synchronous step (a packed table's first evaluation reads its info block back: evaluate it once, or pack it, before capturing)";
+    case RDF_ERR_STALE: return "rdf: a kernel of an earlier call found another packed table at an address than the one this process remembered there (a table was copied over a known address without rdf_forest_forget); what the library knew about this device's tables has been dropped: call again";
     case RDF_ERR_BUILD: return "rdf: this build of the library breaks an assumption of its own kernels (static LDS in a forest kernel); rebuild it";
     default: break;
     }

@@ -130,21 +130,50 @@ class DecisionForest:
 
     def adopt_packed(self, table_bytes, scale_factor=1.):
         """Takes a table `packed_bytes` produced for THIS forest (same trees / depth / classes, same forest_cu contents, same
-        scale) instead of packing: the table is uploaded, the library reads its info block at the first evaluation (a table
-        that rdf_forest_pack of this library version did not write is refused there) and finds the deep-level choice in it."""
+        scale) instead of packing: the table is uploaded and the library reads its info block AT ONCE (`_verify_table`): bytes
+        that this library version's rdf_forest_pack did not write for this shape, or a table packed for another scale than
+        `scale_factor`, raise ValueError here -- not at some later evaluation, where a first look at the table cannot be
+        recorded into a hipGraph, and not never (the library evaluates with the table's own scale, so a wrong cache key would
+        give another scale's labels silently).  The deep-level choice is found in the table."""
         s = float(np.float32(scale_factor))
         rt = get_runtime()
         lib = rt.lib
         nbytes = int(lib.rdf_forest_packed_bytes(int(self.num_trees), int(self.max_depth), int(self.num_classes)))
         table_bytes = np.ascontiguousarray(table_bytes, dtype=np.uint8).reshape(-1)
-        assert table_bytes.size == nbytes, f"packed table of {table_bytes.size} bytes, this forest's is {nbytes}"
+        if table_bytes.size != nbytes:
+            raise ValueError(f"adopt_packed: a packed table of {table_bytes.size} bytes; this forest's "
+                             f"(T{self.num_trees}/D{self.max_depth}/C{self.num_classes}) is {nbytes}")
         hit = self._packed.get(s)
         buf = hit[1] if (hit is not None and hit[1].nbytes == nbytes) else DeviceArray((nbytes,), np.uint8)
         self._forget(buf)               # whatever the library knew about this address
+        self._packed.pop(s, None)       # (nothing half-adopted stays behind a failing check)
         buf.set(table_bytes)
+        self._verify_table(buf, s, "adopt_packed")
         self._packed[s] = ((id(self.forest_cu), self.forest_cu.version), buf)
         self.__dict__.setdefault("_tuned", {}).pop(s, None)
         return buf
+
+    def _verify_table(self, buf, s, who):
+        """The library's first look at a table that arrived by other means than rdf_forest_pack (upload, broadcast): magic,
+        shape and generation are checked by rdf_forest_info, the scale here.  Synchronous (a 128-byte read-back); afterwards the
+        table is known, so a later evaluation can be captured into a hipGraph."""
+        import ctypes
+        rt = get_runtime()
+        lib = rt.lib
+        if not hasattr(lib, "rdf_forest_info"):         # (the host test double)
+            return
+        scale = ctypes.c_float(0.)
+        rc = lib.rdf_forest_info(buf.ptr, int(self.num_trees), int(self.max_depth), int(self.num_classes), rt.stream(), None, None,
+                                 ctypes.byref(scale))
+        if rc != 0:
+            self._forget(buf)
+            msg = lib.rdf_error_string(int(rc))
+            raise ValueError(f"{who}: these bytes are not a packed table of a T{self.num_trees}/D{self.max_depth}/C{self.num_classes} "
+                             f"forest written by this library version's rdf_forest_pack "
+                             f"({msg.decode() if isinstance(msg, bytes) else msg}, code {rc})")
+        if np.float32(scale.value) != np.float32(s):
+            self._forget(buf)
+            raise ValueError(f"{who}: the table was packed for scale_factor {scale.value!r}, not {s!r}")
 
     def deep_from(self, scale_factor=1.):
         """The deep-level choice the packed table of `scale_factor` carries: a level, 0 (heap-order records), or None when
@@ -379,6 +408,30 @@ class DecisionTreeEvaluator:
                           filter_images_class=None, scale_factor=1.):
         self._forest_call(forest, depth_images_in, labels_out, labels_reduce, filter_images, filter_images_class,
                           scale_factor, False)
+
+    def get_labels_forest_split(self, forest, depth_images_in, labels_out, helper_stream, helper_cus, labels_reduce=1,
+                                scale_factor=1., queue_tag=0, fill_untouched=False):
+        """get_labels_forest as TWO launches that share one tile queue (rdf_eval_forest_packed_split): a main launch on the
+        current stream -- meant to be a CU-masked one (rdf_stream_create_with_reserved_cus) -- and a helper launch on
+        `helper_stream` (a raw hipStream_t handle) that the caller has made wait for whatever occupies the `helper_cus` compute
+        units the main stream leaves alone: a multi-GPU step's RCCL gather (distributed.ShardedForestEvaluator).  Packed forests,
+        one C-ABI call (< 2^31 pixels).  Returns the helper launch's workgroups (0: the launch was not split).  Not in the
+        reference (single-GPU)."""
+        import ctypes
+        num_images, dim_y, dim_x = depth_images_in.shape
+        assert tuple(labels_out.shape) == (num_images, dim_y // labels_reduce, dim_x // labels_reduce)
+        assert num_images * dim_y * dim_x <= _PIX_LIMIT, "split launches take one C-ABI call: split the batch"
+        packed = forest.packed(scale_factor)
+        assert packed is not None and forest.max_depth <= 27
+        n_helper = ctypes.c_int(0)
+        rc = self._lib.rdf_eval_forest_packed_split(
+            device_ptr(depth_images_in), int(num_images), int(dim_x), int(dim_y), packed.ptr, device_ptr(forest.forest_cu),
+            int(forest.num_trees), int(forest.max_depth), int(forest.num_classes), None, -1, device_ptr(labels_out),
+            int(labels_reduce), 1 if fill_untouched else 0, self._rt.stream(), ctypes.c_void_p(int(helper_stream)),
+            int(helper_cus), int(queue_tag), ctypes.byref(n_helper))
+        _lib.check(self._lib, rc, "rdf_eval_forest_packed_split")
+        _touch(labels_out)
+        return int(n_helper.value)
 
     def get_labels_forest_filled(self, forest, depth_images_in, labels_out, labels_reduce=1, filter_images=None,
                                  filter_images_class=None, scale_factor=1.):

@@ -58,8 +58,12 @@ def replicate_forest(forest, src=0, group=None, packed_scales=()):
                 hit = forest._packed.get(s)
                 buf = hit[1] if (hit is not None and hit[1].nbytes == nbytes) else DeviceArray((nbytes,), np.uint8)
                 forest._forget(buf)                 # whatever the library knew about this address
+                forest._packed.pop(s, None)
             dist.broadcast(buf.torch_bytes(), src=src, group=group)
             if rank != src:
+                # the library's first look at the received bytes, now (magic, shape, generation; the scale against `s`): a bad
+                # table raises ValueError here instead of evaluating with another scale later (DecisionForest._verify_table)
+                forest._verify_table(buf, s, f"replicate_forest (rank {rank})")
                 forest._packed[s] = ((id(forest.forest_cu), forest.forest_cu.version), buf)
                 forest.__dict__.setdefault("_tuned", {}).pop(s, None)
     return forest
@@ -71,7 +75,7 @@ class ShardedForestEvaluator:
     All ranks must hold shards of the same shape (weak scaling: `frames_per_rank` each)."""
 
     def __init__(self, evaluator, forest, frames_per_rank, depth_dims, labels_reduce=1, scale_factor=1.,
-                 n_chunks=4, dst=0, group=None):
+                 n_chunks=4, dst=0, group=None, helper_cus=0):
         import torch.distributed as dist
 
         self.dist = dist
@@ -93,6 +97,14 @@ class ShardedForestEvaluator:
         self._step_no = 0
         self._inflight = {}
         self.gathered = None
+        # step_overlapped on a CU-masked compute stream (rdf_stream_create_with_reserved_cus): the `helper_cus` compute units the
+        # stream leaves to RCCL's kernel are idle once the gather has finished -- about half of a step.  With helper_cus > 0 every
+        # step is a SPLIT launch (DecisionTreeEvaluator.get_labels_forest_split): the main launch starts at once on the masked
+        # stream, a helper launch on an ordinary stream waits for the previous step's gather and then pulls tiles from the same
+        # queue on the units the gather has left.  No second pass over the frames, no guess at how long the gather takes.
+        self.helper_cus = int(helper_cus)
+        self._helper_stream = None
+        self.helper_workgroups = None      # of the last split step (0: that launch was not split)
         # the gather runs whenever a process group exists -- with one rank too (bench.py --force-distributed puts the RCCL
         # path on a one-GPU box that way); without torch.distributed there is nothing to gather
         self.collective = dist.is_initialized()
@@ -144,7 +156,23 @@ class ShardedForestEvaluator:
             self._inflight[slot] = None
         if prefill is not None:
             labels.fill(prefill)
-        self.ev.get_labels_forest(self.forest, depth, labels, labels_reduce=self.r, scale_factor=self.s)
+        if self.helper_cus > 0:
+            import torch
+            cur = torch.cuda.current_stream()
+            if self._helper_stream is None:
+                self._helper_stream = torch.cuda.Stream()
+            helper = self._helper_stream
+            helper.wait_stream(cur)             # the frames, the fill, the previous step's launches
+            prev = self._inflight.get((slot + 1) % len(labels_ring))       # the gather of step s-1: it holds the reserved CUs
+            if prev is not None:
+                with torch.cuda.stream(helper):
+                    prev.wait()                 # (RCCL: the helper STREAM waits, the host goes on)
+            self.helper_workgroups = self.ev.get_labels_forest_split(
+                self.forest, depth, labels, helper.cuda_stream, self.helper_cus, labels_reduce=self.r, scale_factor=self.s,
+                queue_tag=self._step_no & 1)
+            cur.wait_stream(helper)             # the gather below (and the next step's launch) come after BOTH launches
+        else:
+            self.ev.get_labels_forest(self.forest, depth, labels, labels_reduce=self.r, scale_factor=self.s)
         if self.collective:
             send = self._torch_view(labels, 0, self.frames)
             recv = None

@@ -21,28 +21,43 @@ from .device import DeviceArray, device_ptr, get_runtime
 from .engine.buffer import GpuBuffer
 
 
-_pending = []       # (graph, lib, capture id, device, last replay's event) of replay objects dropped while a capture was under way
+# [graph, lib, capture id, device, last replay's event, capture stream, attempts] of replay objects that were dropped
+_pending = []
+_MAX_RELEASE_ATTEMPTS = 3
 
 
 def _release_deferred():
     """Gives the tile-queue slots of dropped replay objects back (rdf_graph_slots_release) once their last replay has finished;
-    does nothing while the current stream is being captured (the entries wait for the next call)."""
+    does nothing while the current stream is being captured (the entries wait for the next call).  An entry leaves the list
+    only when its slots HAVE been given back: one whose wait or reset raises is tried again at the next call (a few times --
+    then it is dropped with its slots, which is what losing the entry at the first failure used to do silently)."""
     import torch
     try:
         if torch.cuda.is_current_stream_capturing():
             return
     except Exception:       # noqa: BLE001 -- (interpreter shutdown)
         return
+    again = []
     while _pending:
-        g, lib, cid, dev, event = _pending.pop()
+        entry = _pending.pop()
+        g, lib, cid, dev, event, stream, attempts = entry
         try:
             with torch.cuda.device(dev):         # (the slots are keyed by device: the device of the capture is made current)
                 if event is not None:
                     event.synchronize()
+                elif stream is not None:
+                    # never replayed through replay() -- the raw graph may have been (replay.graph): the capture stream is
+                    # where the warm-up ran and the best guess at where such a replay ran; the device, if there is none
+                    stream.synchronize()
+                else:
+                    torch.cuda.synchronize()
                 g.reset()
                 lib.rdf_graph_slots_release(cid)
         except Exception:       # noqa: BLE001 -- a finalizer must not raise
-            pass
+            entry[6] = attempts + 1
+            if entry[6] < _MAX_RELEASE_ATTEMPTS:
+                again.append(entry)
+    _pending.extend(again)
 
 
 class HandPipeline:
@@ -131,7 +146,7 @@ class HandPipeline:
             last[0] = done
             return read_fn() if read else None
         replay.read = read_fn
-        replay.graph = graph
+        replay.graph = graph        # (replay() records the event the release waits for; a bare graph.replay() is not covered by it)
         # the recorded forest launches hold tile-queue slots of their own: given back when the replay object is dropped
         # (the graph goes with it), so that captures over a process's lifetime never run out of them
         if named:
@@ -145,7 +160,7 @@ class HandPipeline:
                 # hand's pipeline is being captured, and a device-wide synchronisation is illegal during a capture (it
                 # would invalidate that capture, and the error would be swallowed here).  While this thread's current
                 # stream is capturing, the release is put off until the next capture() or replay release.
-                _pending.append((g, lib, cid, dev, last[0]))
+                _pending.append([g, lib, cid, dev, last[0], side, 0])
                 _release_deferred()
             replay.release = weakref.finalize(replay, _release)
         return replay

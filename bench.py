@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--trees", type=int, default=4)
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--classes", type=int, default=4)
-    ap.add_argument("--topology", default="full", choices=["full", "trained", "balanced"])
+    ap.add_argument("--topology", default="full", choices=["full", "trained", "balanced", "trainer"],
+                    help="synthetic topologies; `trainer` = the forest the cfg2_trainer_forest leg trained and left in the bench cache")
     ap.add_argument("--chunks", type=int, default=0, help="eval/gather pipeline chunks per step (0: one launch per step; at N>1 the gather then overlaps the NEXT step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,7 +78,7 @@ def parse():
     ap.add_argument("--no-tune", action="store_true", help="do not let DecisionForest.tune choose the deep-level table per forest")
     ap.add_argument("--deep-from", type=int, default=None, help="the headline forest's deep-level table, fixed instead of tuned: 0 = heap-order "
                     "records, N = deep blocks from level N (what tools/profile.sh passes, so that a kernel trace holds the timed launches only)")
-    ap.add_argument("--leg", default=None, choices=["headline", "cfg2", "cfg5", "headline_balanced", "cfg5_balanced"],
+    ap.add_argument("--leg", default=None, choices=["headline", "cfg2", "cfg5", "headline_balanced", "cfg5_balanced", "headline_trainer"],
                     help="internal: run ONE leg and print its kernel time (the program the --pmc passes profile)")
     ap.add_argument("--unpacked", action="store_true", help="evaluate straight from the reference-layout forest")
     ap.add_argument("--scheduler", default="dynamic", choices=["dynamic", "static", "tile"],
@@ -95,6 +96,11 @@ def parse():
                          "`value` is the fastest intact one's; both = the same, `value` is p2p's")
     ap.add_argument("--reserve-cus", type=int, default=-1, help="run the forest kernel on a stream that leaves this many CUs "
                     "(one per shader engine = 32) to RCCL's kernels; -1: 32 with the rccl gather, 0 otherwise (DESIGN.md section 6)")
+    ap.add_argument("--no-split-step", action="store_true", help="RCCL gather mode: one launch per step on the CU-masked stream, "
+                    "without the helper launch that takes the reserved CUs back once the previous step's gather has finished")
+    ap.add_argument("--time-budget", type=float, default=300.0, help="N>1: seconds of wall time (rank 0's clock, from process "
+                    "start) after which the OPTIONAL parts are skipped -- the transports timed beside the RCCL gather, config 5 on "
+                    "all ranks -- and named in distributed.unavailable; the RCCL gather's figure (`value`) is always measured")
     ap.add_argument("--fail-ipc-open-on-rank", type=int, default=None, help="test hook: that rank behaves as if it could not map "
                     "rank 0's receive buffer (the run must fall back to the RCCL gather and say why)")
     ap.add_argument("--force-distributed", action="store_true", help="take the N>1 code path (communicator, gather modes, CU-masked "
@@ -264,7 +270,9 @@ def compact_line(out, full_path=None):
              "hbm_frac_of_gather_ceiling": g(lv, "hbm", "frac_of_gather_ceiling"), "valu_frac": g(lv, "valu", "frac"),
              "l2_hit_rate": r.get("l2_hit_rate"), "clock_ghz": r.get("clock_ghz"),
              "algorithmic_bytes": g(r, "algorithmic", "bytes_per_launch"), "algorithmic_gbs": g(r, "algorithmic", "rate_gbs"),
-             "algorithmic_over_hbm_peak": g(r, "algorithmic", "over_hbm_peak"),
+             # SURVEY 8(d)'s figure as written: algorithmic bytes / kernel time / 8 TB/s.  Above 1 on this workload -- the bytes
+             # are mostly served by LDS, L1 and L2 -- so it is NOT the fraction of any roofline; hbm_frac is the measured one
+             "survey_8d_frac": g(r, "algorithmic", "over_hbm_peak"),
              "copy_ceiling_gbs": g(r, "copy_ceiling", "value"),
              "counters": ("live --pmc passes of this run" if "child passes" in str(r.get("counters_source"))
                           else (str(r.get("counters_source"))[:80] if r.get("counters_source") else None))}
@@ -293,10 +301,12 @@ def compact_line(out, full_path=None):
         "cfg2_balanced_us": us(g(out, "cfg2_balanced", "kernel_ms")),
         "cfg2_trained_us": us(g(out, "cfg2_trained", "kernel_ms")),
         "cfg3_us": us(g(out, "cfg3_layered_run", "ms_per_frame_wall")),
-        "cfg5_mpix": g(out, "cfg5_shard", "value"), "cfg5_ms": g(out, "cfg5_shard", "kernel_ms"),
-        "cfg5_bound": g(out, "cfg5_shard", "roofline", "bound"), "cfg5_frac": g(out, "cfg5_shard", "roofline", "frac"),
-        "cfg5_hbm_frac": g(out, "cfg5_shard", "roofline", "levels", "hbm", "frac"),
-        "cfg5_differing_pixels": g(out, "cfg5_shard", "parity", "differing_pixels"),
+        # config 5's shard twice: `cfg5_full_*` on SURVEY 8(d)'s synthetic "full" forest (walks bunch up: cache-resident, NOT the
+        # HBM-bound point), `cfg5_balanced_*` on a forest whose deep levels are occupied (3.6 GiB of tables: HBM-resident)
+        "cfg5_full_mpix": g(out, "cfg5_shard", "value"), "cfg5_full_ms": g(out, "cfg5_shard", "kernel_ms"),
+        "cfg5_full_bound": g(out, "cfg5_shard", "roofline", "bound"), "cfg5_full_frac": g(out, "cfg5_shard", "roofline", "frac"),
+        "cfg5_full_hbm_frac": g(out, "cfg5_shard", "roofline", "levels", "hbm", "frac"),
+        "cfg5_full_differing_pixels": g(out, "cfg5_shard", "parity", "differing_pixels"),
         "cfg5_balanced_mpix": g(out, "cfg5_balanced", "value"), "cfg5_balanced_ms": g(out, "cfg5_balanced", "kernel_ms"),
         "cfg5_balanced_bound": g(out, "cfg5_balanced", "roofline", "bound"),
         "cfg5_balanced_frac": g(out, "cfg5_balanced", "roofline", "frac"),
@@ -311,6 +321,9 @@ def compact_line(out, full_path=None):
         "unpacked_mpix": g(out, "unpacked", "value"),
         "trained_batch_mpix": g(out, "cfg2_trained", "batch", "value"),
         "trainer_forest_mpix": g(out, "cfg2_trainer_forest", "value"),
+        "trainer_forest_bound": g(out, "cfg2_trainer_forest", "roofline", "bound"),
+        "trainer_forest_frac": g(out, "cfg2_trainer_forest", "roofline", "frac"),
+        "trainer_forest_hbm_frac": g(out, "cfg2_trainer_forest", "roofline", "levels", "hbm", "frac"),
         "hand_pipeline_us": g(out, "hand_pipeline", "us_per_hand_per_frame_as_hipgraph"),
         "train_seconds": g(out, "train", "seconds"),
         "cpu_baseline_numpy_mpix": g(out, "cpu_baseline_numpy", "value"),
@@ -325,7 +338,7 @@ def compact_line(out, full_path=None):
             "backend": dd.get("backend"), "rccl_ranks": dd.get("rccl_ranks"), "distinct_devices": dd.get("distinct_devices"),
             "device_indices": [d_.get("device_index") for d_ in dd.get("devices") or []],
             "kernel_only_ms": dd.get("kernel_only_ms"), "value_kernel_only": dd.get("value_kernel_only"),
-            "gather_modes": {n: {k: m.get(k) for k in ("ms_per_step", "value", "gather_check", "cus_left_to_rccl") if k in m}
+            "gather_modes": {n: {k: m.get(k) for k in ("ms_per_step", "value", "gather_check", "cus_left_to_rccl", "split_step_helper_workgroups") if k in m}
                              for n, m in (dd.get("gather_modes") or {}).items()},
             "unavailable": {k: str(v)[:160] for k, v in (dd.get("unavailable") or {}).items()},
             "total_seconds": dd.get("total_seconds")}
@@ -343,7 +356,7 @@ def compact_line(out, full_path=None):
     for drop in (None, "leg_errors", "cfg5_all_ranks", "legs", "distributed.unavailable", "cpu_baseline.sample", "config.workload"):
         if drop == "legs":
             for k in legs:
-                if k not in ("value_balanced", "cfg2_us", "cfg3_us", "cfg5_mpix", "cfg5_balanced_mpix", "cfg5_balanced_hbm_frac"):
+                if k not in ("value_balanced", "cfg2_us", "cfg3_us", "cfg5_full_mpix", "cfg5_balanced_mpix", "cfg5_balanced_hbm_frac"):
                     line.pop(k, None)
         elif drop and "." in drop:
             a_, b_ = drop.split(".")
@@ -688,7 +701,14 @@ def main():
     H, W, F, T, D, C = a.height, a.width, a.frames, a.trees, a.depth, a.classes
     if a.leg == "headline_balanced":        # (the batch of the headline on the balanced forest: what the --pmc passes of cfg2_balanced profile)
         a.topology, a.leg = "balanced", "headline"
-    forest_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_{a.topology}", lambda: synth.forest(T, D, C, a.topology)))
+    if a.leg == "headline_trainer":         # (... on the forest this run's cfg2_trainer_forest leg trained: round 6)
+        a.topology, a.leg = "trainer", "headline"
+
+    def make_forest():
+        if a.topology == "trainer":
+            raise SystemExit(f"--topology trainer: no forest_T{T}_D{D}_C{C}_trainer in the bench cache (the cfg2_trainer_forest leg of a default run leaves it there)")
+        return synth.forest(T, D, C, a.topology)
+    forest_np = np.asarray(cached(f"forest_T{T}_D{D}_C{C}_{a.topology}", make_forest))
     forest = rdf.DecisionForest.from_numpy(forest_np)
     frames_np = np.asarray(cached(f"frames_mixed_{F}_{H}x{W}_at{rank * F}", lambda: synth.mixed_batch(F, first_idx=rank * F, h=H, w=W)))
     depth = rdf.to_device(frames_np)
@@ -846,17 +866,36 @@ def main():
         if why:
             notes["cu_masked_stream"] = f"unavailable: {why}"
         handles.append(h)
+        # split steps (round 6): the CUs the masked stream leaves to RCCL are idle once the previous step's gather has finished;
+        # a helper launch that waits for that gather takes them back and pulls tiles from the main launch's queue
+        sharded.helper_cus = reserve if (st is not None and overlapped and not a.no_split_step and not a.unpacked) else 0
         step = (lambda: sharded.step_overlapped(depth, ring)) if overlapped else (lambda: sharded.step(depth, labels))
         return (step, sharded.drain, st, reserve if st is not None else 0, sharded.result, False)
+
+    def over_budget(what):
+        """N>1: has the run used up its wall-time budget?  Rank 0's clock decides for every rank (one broadcast), and what is
+        skipped is named on the line (distributed.unavailable)."""
+        if not multi:
+            return False
+        flag = [bool(time.perf_counter() - t_main > a.time_budget)]
+        dist.broadcast_object_list(flag, src=0)
+        if flag[0]:
+            notes[what] = f"skipped: the {a.time_budget:.0f}-s wall-time budget of the N>1 run was spent before it (--time-budget)"
+        return flag[0]
 
     if not multi:
         modes["none"] = (lambda: sharded.step(depth, labels), sharded.drain, None, 0, None, False)
     else:
+        # (the RCCL gather first where it is `value` -- every choice but "both" and "p2p": it is never the part the wall-time
+        # guard skips)
+        want_rccl = peer is None or a.gather in ("rccl", "both", "auto", "fastest")
+        if want_rccl and a.gather != "both":
+            modes["rccl gather"] = rccl_mode()
         if peer is not None and a.gather != "rccl":
             modes["p2p copy engines"] = (lambda: peer.step(depth, ring), peer.drain, None, 0, peer.result, True)
         if peer_direct is not None:
             modes["p2p direct stores"] = (lambda: peer_direct.step(depth, None), peer_direct.drain, None, 0, peer_direct.result, True)
-        if "p2p copy engines" not in modes or a.gather in ("rccl", "both", "auto", "fastest"):
+        if want_rccl and "rccl gather" not in modes:
             modes["rccl gather"] = rccl_mode()
     torch.cuda.synchronize()
 
@@ -864,6 +903,8 @@ def main():
     queue = list(modes.items())
     while queue:
         name, (step, drain, st, reserve, result_fn, from_peer) = queue.pop(0)
+        if results and over_budget(name):           # (never the first mode)
+            continue
         elapsed, kms, failed = timed(step, drain, st)
         if failed is None and multi:
             try:
@@ -880,6 +921,8 @@ def main():
                 queue.append(("rccl gather", modes["rccl gather"]))
             continue
         results[name] = {"elapsed": elapsed, "kern_ms": kms, "reserve": reserve, "gather_check": check}
+        if name == "rccl gather" and sharded.helper_cus > 0:
+            results[name]["split_step_helper_workgroups"] = sharded.helper_workgroups
         if name in ("p2p copy engines", "p2p direct stores") and rank == 0:
             # the ring's ready counters after the drain: the last two steps of every rank are marked as landed
             try:
@@ -981,13 +1024,15 @@ def main():
                               "gather_modes": {n: {"ms_per_step": round(r["elapsed"] / a.steps * 1e3, 4),
                                                    "value": round(pix_per_step * a.steps / r["elapsed"] / 1e6, 2),
                                                    "cus_left_to_rccl": r["reserve"], "gather_check": r["gather_check"],
+                                                   **({"split_step_helper_workgroups": r["split_step_helper_workgroups"]}
+                                                      if "split_step_helper_workgroups" in r else {}),
                                                    **({"ready_counters_ok": r["ready_counters_ok"]} if "ready_counters_ok" in r else {})}
                                                for n, r in results.items()},
                               # what this run could not use, and why (p2p: the receive ring could not be mapped by every rank;
                               # cu_masked_stream: the RCCL gather then ran beside a kernel on all CUs; a mode that failed mid-run)
                               "unavailable": notes}
 
-        if not a.no_cfg5:
+        if not a.no_cfg5 and not over_budget("cfg5_all_ranks"):
             try:
                 c5n = leg_cfg5_all_ranks(5, 2)       # every rank takes part
             except Exception as e:   # noqa: BLE001 -- the headline is measured; it must still be printed
@@ -1315,9 +1360,34 @@ def main():
             leg("unpacked", leg_unpacked)
             leg("cfg2_trained", leg_trained)
             if not a.no_balanced and not a.unpacked:
-                leg("cfg2_trainer_forest", lambda: bench_legs.trainer_forest(
-                    rdf, frames_np, T, D, train_frames=np.asarray(cached(f"frames_mixed_64_{H}x{W}_at20000",
-                                                                        lambda: synth.mixed_batch(64, first_idx=20000, h=H, w=W)))))
+                def leg_trainer_forest():
+                    """A forest from this repo's own trainer on the bench batch (tools/bench_legs.py), and -- round 6 -- its own
+                    counter passes: the trained forest and the table tune() chose go into the bench cache, `--leg
+                    headline_trainer` child processes (one per counter set) evaluate the same batch on it, and the leg gets a
+                    roofline of its own like the synthetic topologies."""
+                    res, tf_np = bench_legs.trainer_forest(
+                        rdf, frames_np, T, D, return_forest=True,
+                        train_frames=np.asarray(cached(f"frames_mixed_64_{H}x{W}_at20000", lambda: synth.mixed_batch(64, first_idx=20000, h=H, w=W))))
+                    if C != 4 or a.no_counters or not live:
+                        return res
+                    try:
+                        os.makedirs(CACHE, exist_ok=True)
+                        np.save(os.path.join(CACHE, f"forest_T{T}_D{D}_C{C}_trainer.npy"), tf_np)
+                        run_id = os.environ.get("RDF_BENCH_RUN_ID")
+                        json.dump(res["tune"], open(os.path.join(CACHE, f"tune_{run_id}_T{T}_D{D}_C{C}_trainer_{H}x{W}_F{F}.json"), "w"))
+                        ft = rdf.DecisionForest.from_numpy(tf_np)
+                        ft.packed(1.0)
+                        assert lib.rdf_forest_set_deep_from(ft.packed(1.0).ptr, int(res["tune"]["deep_from"])) == 0
+                        useful_t, st8_t = useful_lines(ft, depth)
+                        alg_t = synth.algorithmic_bytes(F, H, W, 1, False, C, st8_t[0:3]) if st8_t else None
+                        del ft
+                        live_t = collect_counters(a, ["headline_trainer"])
+                        res["roofline"] = roofline_for("headline_trainer", f"F{F}_T{T}_D{D}_C{C}_trainer", live_t, res["ms_per_step"], alg_t, useful_t)
+                        res["counter_pass_seconds"] = live_t["headline_trainer"]["seconds"]
+                    except Exception as e:   # noqa: BLE001 -- the leg's timing and parity stand without its counters
+                        res["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    return res
+                leg("cfg2_trainer_forest", leg_trainer_forest)
             leg("hand_pipeline", lambda: bench_legs.hand_pipeline(rdf))
             leg("mean_shift", lambda: bench_legs.mean_shift(rdf))
             leg("train", lambda: bench_legs.train(rdf))

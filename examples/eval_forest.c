@@ -53,6 +53,36 @@ int main(void)
         const unsigned want = (i == 5 || i == 17) ? 65535u : 1u;
         if (labels[i] != want) ++bad;
     }
+    /* The life of a packed table (include/rdf_hip.h, "Load-time repack"): allocate rdf_forest_packed_bytes(), pack once at model
+     * load, evaluate from it as often as needed, and TELL the library before the memory goes away -- it remembers what it read
+     * from a table's info block per (device, address), and an allocation that later lands on the same address must not meet
+     * that memory (a consumer that forgets is told: the call after such a launch returns RDF_ERR_STALE). */
+    {
+        void *d_packed = NULL;
+        const size_t nbytes = rdf_forest_packed_bytes(1, 1, 2);
+        float scale = 0.f;
+        int exact = -1;
+        if (nbytes == 0 || hipMalloc(&d_packed, nbytes) != hipSuccess) ++bad;       /* (hipMalloc is 256-byte aligned: >= the 128 needed) */
+        else {
+            hipMemcpy(d_labels, memset(labels, 0xFF, sizeof labels), sizeof labels, hipMemcpyHostToDevice);
+            rc = rdf_forest_pack((const float *)d_forest, 1, 1, 2, 1.0f, d_packed, NULL);
+            if (rc == RDF_OK) rc = rdf_forest_info(d_packed, 1, 1, 2, NULL, NULL, &exact, &scale);
+            if (rc == RDF_OK)
+                rc = rdf_eval_forest_packed((const uint16_t *)d_depth, 1, W, H, d_packed, (const float *)d_forest, 1, 1, 2, NULL, -1,
+                                            (uint16_t *)d_labels, 1, NULL);
+            if (rc != RDF_OK) {
+                fprintf(stderr, "packed path: %s\n", rdf_error_string(rc));
+                ++bad;
+            }
+            hipDeviceSynchronize();
+            hipMemcpy(labels, d_labels, sizeof labels, hipMemcpyDeviceToHost);
+            for (i = 0; i < H * W; ++i)
+                if (labels[i] != ((i == 5 || i == 17) ? 65535u : 1u)) ++bad;
+            if (scale != 1.0f || exact != 0) ++bad;
+            if (rdf_forest_forget(d_packed) != RDF_OK) ++bad;      /* before the free */
+            hipFree(d_packed);
+        }
+    }
     /* argument errors come back as negative codes, not as faults */
     if (rdf_eval_forest(NULL, 1, W, H, (const float *)d_forest, 1, 1, 2, NULL, -1, (uint16_t *)d_labels, 1, 1.0f, NULL) !=
         RDF_ERR_NULL_PTR)

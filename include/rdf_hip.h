@@ -31,8 +31,10 @@ extern "C" {
  * new: rdf_set_deep_from, rdf_forest_set_deep_from, rdf_forest_tune, rdf_eval_forest_packed_stats.  Nothing was removed or re-typed.
  * 4: the choice of rdf_forest_set_deep_from / rdf_forest_tune is kept IN the packed table (its info block) and a table nobody
  * chose for is walked from the heap-order records (version 3 chose by forest size); new: rdf_forest_info,
- * rdf_forest_forget, rdf_build_id, RDF_ERR_CAPTURE (was RDF_ERR_BAD_ARG).  Nothing was removed or re-typed; table sizes unchanged. */
-#define RDF_ABI_VERSION 4
+ * rdf_forest_forget, rdf_build_id, RDF_ERR_CAPTURE (was RDF_ERR_BAD_ARG).  Nothing was removed or re-typed; table sizes unchanged.
+ * 5: a packed table's info block carries the shape it was packed for and a generation number (tables of version 4 are refused:
+ * re-pack); new: RDF_ERR_STALE, rdf_eval_forest_packed_split.  Nothing was removed or re-typed; table sizes unchanged. */
+#define RDF_ABI_VERSION 5
 
 #define RDF_OK 0
 #define RDF_ERR_BAD_ARG (-1)     /* negative size, labels_reduce < 1, max_depth outside [0,30] ... */
@@ -44,6 +46,15 @@ extern "C" {
 #define RDF_ERR_CAPTURE (-6)     /* `stream` is being captured into a hipGraph and the call needs a synchronous step: the FIRST
                                     evaluation of a packed table this process has not seen at this address reads the table's info
                                     block back (evaluate once, or rdf_forest_pack, before capturing) */
+#define RDF_ERR_STALE (-7)       /* a kernel of an EARLIER call on this device found, at a packed table's address, another table than
+                                    the one this process remembered there -- a different table was written over a known address by
+                                    other means than rdf_forest_pack and rdf_forest_forget was not called.  Every packing carries a
+                                    generation number in its info block; every launch carries the number the host remembers and
+                                    compares the two on the device (no synchronous read).  That earlier call's labels are right
+                                    unless the new table holds nodes that need the exact numerators and the call passed no `forest`
+                                    (the kernel reads the scale from the table itself, never from the host's memory).  The library
+                                    has dropped everything it knew about this device's tables when it returns this code: call
+                                    again, and the info blocks are read afresh. */
 
 /*
  * Forest evaluation.  Replaces `evaluate_image_using_forest`
@@ -185,10 +196,17 @@ int rdf_eval_forest_packed_stats(const uint16_t *depth, int n_img, int dim_x, in
  * fastest (the deep blocks must beat the heap-order records by 2 %: a tie goes to the default) and reports what it tried
  * (up to 12 entries in levels_tried / ms_tried, all three outputs nullable).  Synchronous; tune once per table, at load time.
  * Labels do not depend on the choice.  The process-wide knob rdf_set_deep_from (>= 0) overrides both.
- * rdf_forest_forget drops what the host remembers about the table at `packed` (scale, exact-node count, choice): call it
+ * rdf_forest_forget drops what the host remembers about the table at `packed` (exact-node count, choice, generation): call it
  * before freeing a packed table, or after writing a DIFFERENT packed table to an address this process has evaluated from by
  * any means other than rdf_forest_pack (device-to-device copy, IPC mapping) -- the next evaluation then reads the info block
- * again.  Without it such a table would be evaluated with the old table's scale.
+ * again.  A consumer that forgets to is told (round 6): the kernels compare the table's generation word with the one the
+ * host remembers and the call after such a launch returns RDF_ERR_STALE (see there); the scale is read by the kernel from the
+ * table itself, so even that launch's labels are the new table's.  The life of a table in a C program:
+ *     hipMalloc(&packed, rdf_forest_packed_bytes(T, D, C));  rdf_forest_pack(forest, T, D, C, s, packed, stream);
+ *     [rdf_forest_tune(...) once]  rdf_eval_forest_packed(...) ...  rdf_forest_forget(packed);  hipFree(packed);
+ * (examples/eval_forest.c).  rdf_forest_set_deep_from and rdf_forest_tune WRITE to the table (`packed` is const for the
+ * evaluation calls only): a synchronous 4-byte copy, device-wide -- load-time calls, not to be made while another thread
+ * captures a hipGraph in global mode.  All four calls find the table's device from the pointer, not from the current device.
  */
 int rdf_forest_set_deep_from(const void *packed, int level);
 int rdf_forest_info(const void *packed, int n_trees, int max_depth, int n_classes, void *stream, int *deep_from,
@@ -216,6 +234,32 @@ int rdf_eval_forest_packed_filled(const uint16_t *depth, int n_img, int dim_x, i
                                   int n_trees, int max_depth, int n_classes,
                                   const uint16_t *filter, int filter_class,
                                   uint16_t *labels_out, int labels_reduce, void *stream);
+
+/*
+ * One evaluation as TWO launches that share one tile queue: a main launch on `stream` and a helper launch on `helper_stream`.
+ * For multi-GPU steps whose label gather is an RCCL kernel (no reference counterpart: the reference is single-GPU,
+ * src/engine/window.py:45-46): RCCL's send/recv kernel cannot start next to the forest kernel's persistent workgroups unless some
+ * compute units are left to it (rdf_stream_create_with_reserved_cus), and those units are idle for the part of the step the
+ * gather does not need.  Here `stream` is the CU-masked stream -- the main launch starts at once on the units it may use -- and
+ * the caller makes `helper_stream` (an ordinary stream) wait for the previous step's gather before this call: the helper's
+ * workgroups then start on the units the gather has just left and pull tiles from the same queue until it is empty, however
+ * early or late they arrive (a helper that arrives after the main launch has finished finds the queue empty and retires).
+ *   helper_cus    compute units the helper may count on (its grid is this many times the workgroups one unit holds); 0: one
+ *                 ordinary launch
+ *   queue_tag     0..3: which of `stream`'s split queue slots the two launches share.  A slot must not be used by a later
+ *                 call before BOTH launches of this one have finished: alternate the tag from step to step, or order the next
+ *                 call on `stream` after `helper_stream`
+ *   fill_untouched  as rdf_eval_forest_packed_filled
+ *   helper_workgroups (out, nullable)  workgroups the helper launch got; 0: the launch was not split (it fits one round of
+ *                 the main launch, or the scheduler is not the dynamic one)
+ * Labels are the same as rdf_eval_forest_packed's.  Not recordable into a hipGraph (RDF_ERR_CAPTURE).
+ */
+int rdf_eval_forest_packed_split(const uint16_t *depth, int n_img, int dim_x, int dim_y,
+                                 const void *packed, const float *forest,
+                                 int n_trees, int max_depth, int n_classes,
+                                 const uint16_t *filter, int filter_class,
+                                 uint16_t *labels_out, int labels_reduce, int fill_untouched,
+                                 void *stream, void *helper_stream, int helper_cus, int queue_tag, int *helper_workgroups);
 
 /*
  * Visit counters for the roofline figure: same walk as rdf_eval_forest, labels_out
@@ -405,9 +449,15 @@ int rdf_debug_div_f32(const float *num, const float *den, float *out, size_t n, 
  * out[3] nanoseconds inside rdf_layered_run[_hand] from entry to return (runtime included), out[4] such calls.  `out` nullable. */
 int rdf_debug_host_overhead(unsigned long long out[5], int reset);
 
-/* Tuning knobs (process-wide atomics, each read once per call; 0 restores the default).  Not part of the reference
- * surface.  The RDF_* environment variables that name the same choices are read once per process, at the first call that
- * looks at them; a knob set through these functions wins. */
+/* Tuning knobs for measurements and tests.  Not part of the reference surface, and NOT part of the re-entrancy promise the
+ * evaluation calls make: every knob is ONE process-wide atomic int, read once per call, so a change is seen by every
+ * thread, stream and device of the process from its next call on (a call that overlaps a change sees the old or the new
+ * value, never a torn one).  Labels never depend on a knob -- only launch geometry and which table is walked -- so a program
+ * that evaluates on several threads stays correct whatever a knob is set to, but it cannot give two of its threads two
+ * settings: leave the knobs alone in such a program (the per-table choice, rdf_forest_set_deep_from / rdf_forest_tune, is the
+ * production interface for the one choice that matters).  0 or -1 restores the default as noted.  The RDF_* environment
+ * variables that name the same choices are read once per process, at the first call that looks at them; a knob set through
+ * these functions wins. */
 void rdf_set_lds_budget_bytes(int bytes);
 void rdf_set_block_threads(int threads); /* 256 or 512; anything else: the default (512 for launches that fill the chip) */
 void rdf_set_compaction(int mode);       /* -1 (default): filtered launches list their pixels first; 0: never */
@@ -436,6 +486,9 @@ void rdf_set_deep_from(int level);       /* packed forests of up to eight classe
                                             lanes' blocks together): -1 = each table's own choice (rdf_forest_set_deep_from /
                                             rdf_forest_tune; none: never), 0 = never, > 0 = from this level on (rounded up to a
                                             block root; never inside the levels held in LDS).  Same labels either way. */
+void rdf_set_fold(int on);               /* a label map whose width leaves at most 32 columns beyond a multiple of 64 (848 = 13 x 64 + 16)
+                                            gets narrow tiles for them, in which a wave covers 2 rows x 32 or 4 rows x 16 pixels,
+                                            instead of a tile column whose waves run mostly empty: 1/-1 (default) on, 0 off */
 /* hipEvent timing on the caller's stream (bench.py times the stream the kernels run on). */
 int rdf_event_create(void **event);
 int rdf_event_record(void *event, void *stream);

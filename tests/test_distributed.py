@@ -74,6 +74,17 @@ def test_two_rank_gather_matches_oracle(n_chunks, tmp_path, oracle):
     assert (tmp_path / "ok").exists()
 
 
+def test_eight_rank_gather_matches_oracle(tmp_path, oracle):
+    """BASELINE configs 4 and 5 run on EIGHT ranks, and no GPU box this build can lease holds more than one card (nor lets more
+    than six processes touch it: the four-rank rehearsal of bench.py is the widest the GPU suite can go).  So the eight-rank
+    shape of the sharded path -- shard_range over 8, rank-indexed receive buffer [8, frames, ...], eight senders in one gather,
+    the cross-step overlap with two label buffers -- is rehearsed here, on the CPU, with gloo and the host double: every
+    shard as rank 0 received it equals the oracle's labels for that shard's frames."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(8, _free_port(), 0, str(tmp_path)), nprocs=8, join=True)
+    assert (tmp_path / "ok").exists()
+
+
 def _replicate_worker(rank, world, port, tmpdir):
     import torch.distributed as dist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

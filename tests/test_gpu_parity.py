@@ -323,6 +323,41 @@ def test_batch_properties_at_scale(rdf, evs, gpu_runtime):
         assert np.array_equal(one.get()[0], A[i])
 
 
+def test_config4_shard_bit_exact(rdf, evs, oracle, gpu_runtime):
+    """BASELINE configs[3]'s per-GPU shard exactly as the benchmark runs it: 128 frames of 848x480, half
+    dense and half live-like, T4/D20/C4 "full" forest, one launch -- EVERY frame against the oracle (a few seconds of
+    oracle/rdf_oracle.c on the box's cores), with the visit counters, through the packed tables (heap-order records and deep
+    blocks) and the reference layout.  bench.py makes the same comparison inside every default run; this puts it into -m gpu."""
+    synth = rdf.synth
+    forest_np = synth.forest(4, 20, 4, "full")
+    host = synth.mixed_batch(128)
+    assert host.shape == (128, 480, 848)
+    want = np.full(host.shape, 65535, np.uint16)
+    st = np.zeros(3, np.uint64)
+    oracle.eval_forest(host, forest_np, want, stats=st)
+    assert 0.4 * host.size < int(st[0]) < 0.7 * host.size and int(st[1]) == 20 * 4 * int(st[0])      # every walk reaches level D-1
+    forest = rdf.DecisionForest.from_numpy(forest_np)
+    depth = rdf.to_device(host)
+    out = rdf.DeviceArray(host.shape, np.uint16)
+    lib = gpu_runtime.lib
+    try:
+        for name, ev, deep in (("packed", evs["packed"], 0), ("packed, deep blocks from level 12", evs["packed"], 12), ("reference layout", evs["direct"], -1)):
+            lib.rdf_set_deep_from(deep)
+            out.fill(65535)
+            ev.get_labels_forest(forest, depth, out)
+            got = out.get()
+            assert np.array_equal(got, want), (name, int((got != want).sum()))
+        lib.rdf_set_deep_from(-1)
+        # the launch's own counters (the roofline's algorithmic bytes come from them) equal the oracle's
+        dstats = rdf.DeviceArray((8,), np.uint64).fill(0)
+        out.fill(65535)
+        rc = lib.rdf_eval_forest_packed_stats(depth.ptr, 128, 848, 480, forest.packed(1.0).ptr, forest.forest_cu.ptr, 4, 20, 4, out.ptr, 1,
+                                              dstats.ptr, gpu_runtime.stream())
+        assert rc == 0 and [int(v) for v in dstats.get()[0:3]] == [int(v) for v in st] and np.array_equal(out.get(), want)
+    finally:
+        lib.rdf_set_deep_from(-1)
+
+
 def test_fill_u16_any_alignment(rdf, gpu_runtime):
     lib, st = gpu_runtime.lib, gpu_runtime.stream()
     buf = rdf.DeviceArray((5000,), np.uint16)
@@ -426,12 +461,14 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
             lib.rdf_set_tree_waves(int(rng.choice([-1, -1, 0, 1])))
             lib.rdf_set_last_level_table(int(rng.choice([-1, -1, 0])))
             lib.rdf_set_deep_from(int(rng.choice([-1, 0, 1, 4, 7, 10])))
+            lib.rdf_set_fold(int(rng.choice([-1, -1, 0])))
             want = np.full((n, h // r, w // r), prefill, np.uint16)
             oracle.eval_forest(depth, forest, want, r, filt, 2 if use_filter else None, s)
             for path in ("packed", "direct"):
                 got = _gpu_forest(rdf, evs[path], depth, forest, prefill, r, filt, 2 if use_filter else None, s)
                 assert np.array_equal(got, want), f"iteration {it} ({path}): T{T} D{D} C{C} {n}x{h}x{w} r{r} s{s}"
     finally:
+        lib.rdf_set_fold(-1)
         lib.rdf_set_block_threads(0)
         lib.rdf_set_halo(-1)
         lib.rdf_set_lds_levels(-1)
@@ -442,6 +479,60 @@ def test_fuzz_against_oracle(rdf, evs, oracle, gpu_runtime):
         lib.rdf_set_lds_budget_bytes(0)
         lib.rdf_set_tree_waves(-1)
         lib.rdf_set_last_level_table(-1)
+        lib.rdf_set_deep_from(-1)
+
+
+@pytest.mark.parametrize("w,r", [(848, 1), (80, 1), (144, 1), (96, 1), (160, 1), (65, 1), (100, 1), (128, 1), (848, 2), (352, 2), (200, 3)])
+def test_narrow_tiles_for_the_last_columns(w, r, rdf, evs, oracle, gpu_runtime):
+    """Round 6: a label map that is 1 to 32 columns wider than a multiple of 64 gets narrow tiles for those columns (a wave =
+    4 rows x 16 or 2 rows x 32 pixels) instead of a column of tiles whose waves run mostly empty -- 848 = 13 x 64 + 16 is every
+    frame of the metric.  Same labels as the oracle's on every route a launch can take: packed and reference layout, one frame
+    (small launch: a wave per tree, or four trees per lane) and a batch that fills the chip (512-thread workgroups), a filter
+    (pixel lists), deep blocks, the fused fill; heights that are no multiple of the narrow tile's rows; and with the knob off."""
+    lib = gpu_runtime.lib
+    h = 101 if w < 400 else 480
+    forest = rdf.synth.forest(4, 9, 4, "trained", 40 + w)
+    n_big = 24 if w >= 352 else 400
+    depth = rdf.synth.mixed_batch(n_big, 1200 + w, h, w)
+    lh, lw = h // r, w // r
+    rem = lw % 64
+    assert (0 < rem <= 32 and lw > 64) == ((w, r) in ((848, 1), (80, 1), (144, 1), (96, 1), (160, 1), (65, 1), (200, 3))), (lw, rem)
+    want = np.full((n_big, lh, lw), 65535, np.uint16)
+    oracle.eval_forest(depth, forest, want, r)
+    filt = (np.arange(n_big * lh * lw).reshape(n_big, lh, lw) % 3).astype(np.uint16)
+    want_f = np.full((n_big, lh, lw), 7, np.uint16)
+    oracle.eval_forest(depth, forest, want_f, r, filt, 1)
+    f = rdf.DecisionForest.from_numpy(forest)
+    d = rdf.to_device(depth)
+    fd = rdf.to_device(filt)
+    try:
+        for fold in (-1, 0):
+            lib.rdf_set_fold(fold)
+            for path in ("packed", "direct"):
+                ev = evs[path]
+                for n in (1, n_big):                                  # a small launch and one that fills the chip
+                    for tw in ((-1, 0) if n == 1 and path == "packed" else (-1,)):
+                        lib.rdf_set_tree_waves(tw)
+                        out = rdf.DeviceArray((n, lh, lw), np.uint16).fill(65535)
+                        ev.get_labels_forest(f, d[0:n], out, r)
+                        got = out.get()
+                        assert np.array_equal(got, want[0:n]), (fold, path, n, tw, int((got != want[0:n]).sum()))
+                    out = rdf.DeviceArray((n, lh, lw), np.uint16).fill(7)
+                    ev.get_labels_forest(f, d[0:n], out, r, fd[0:n], 1)
+                    got = out.get()
+                    assert np.array_equal(got, want_f[0:n]), (fold, path, n, "filter", int((got != want_f[0:n]).sum()))
+            out = rdf.DeviceArray((n_big, lh, lw), np.uint16).fill(12345)
+            evs["packed"].get_labels_forest_filled(f, d, out, r)
+            assert np.array_equal(out.get(), want), (fold, "filled")
+            lib.rdf_set_deep_from(4)
+            for n in (1, n_big):
+                out = rdf.DeviceArray((n, lh, lw), np.uint16).fill(65535)
+                evs["packed"].get_labels_forest(f, d[0:n], out, r)
+                assert np.array_equal(out.get(), want[0:n]), (fold, "deep", n)
+            lib.rdf_set_deep_from(-1)
+    finally:
+        lib.rdf_set_fold(-1)
+        lib.rdf_set_tree_waves(-1)
         lib.rdf_set_deep_from(-1)
 
 
@@ -1051,7 +1142,7 @@ def test_last_level_table_is_taken_only_when_every_deepest_node_is_an_ordinary_o
     # the info block: nodes that need the exact numerators (they are read from the caller's forest), the scale, the mark
     info = packed.get()[packed.nbytes - 128:][:12]
     assert int(info[0:4].view(np.uint32)[0]) == (1 if spoil == "huge_numerator" else 0)
-    assert float(info[4:8].view(np.float32)[0]) == 1.0 and int(info[8:12].view(np.uint32)[0]) == 0x52444634
+    assert float(info[4:8].view(np.float32)[0]) == 1.0 and int(info[8:12].view(np.uint32)[0]) == 0x52444635
     assert unusable == (1 if spoil in ("continue_flag", "huge_numerator") else 0)
     # word 1: the deepest nodes some parent continues to (the default takes the table from half of the level on)
     to_child = f_np[:, first // 2:first, 5:7].reshape(trees, -1)
@@ -1488,13 +1579,19 @@ def test_untuned_table_walks_heap_order_records_and_a_choice_travels_with_the_ta
     again = rdf.DecisionForest.from_numpy(forest_np)
     again.adopt_packed(k.packed_bytes(1.0), 1.0)
     assert again.deep_from() == 11
-    # memory that is not a packed table of this shape is refused at the first look
+    # memory that is not a packed table of this shape is refused at the first look -- which adopt_packed takes at once (round 6):
+    # zeros, a table of another shape's size cut to fit, a table packed for another scale
     junk = rdf.DecisionForest.from_numpy(forest_np)
-    junk.adopt_packed(np.zeros_like(table), 1.0)
-    with pytest.raises(rdf.RdfError):
-        junk.deep_from()
-    with pytest.raises(rdf.RdfError):
-        ev.get_labels_forest(junk, depth[0:1], out[0:1])
+    with pytest.raises(ValueError, match="not a packed table"):
+        junk.adopt_packed(np.zeros_like(table), 1.0)
+    assert junk._packed == {} and junk.deep_from() is None
+    with pytest.raises(ValueError, match="bytes"):
+        junk.adopt_packed(table[:-128], 1.0)
+    with pytest.raises(ValueError, match="packed for scale_factor 1.0"):
+        junk.adopt_packed(table, 0.5)
+    assert junk._packed == {}
+    ev.get_labels_forest(junk, depth[0:1], out[0:1])                # (packs its own table and goes on)
+    assert np.array_equal(out[0:1].get(), want[0:1])
 
 
 def test_a_table_that_lands_on_a_known_address_is_read_afresh(rdf, oracle, gpu_runtime):
@@ -1515,7 +1612,11 @@ def test_a_table_that_lands_on_a_known_address_is_read_afresh(rdf, oracle, gpu_r
     want1 = np.full(depth_np.shape, 65535, np.uint16)
     oracle.eval_forest(depth_np, forest_np, want1, 1, None, None, 1.0)
     assert np.array_equal(out.get(), want1)
-    same_buf = f.adopt_packed(table_half, 1.0)                      # (keyed 1.0 on the Python side: the TABLE says 0.5)
+    with pytest.raises(ValueError, match="packed for scale_factor 0.5"):      # (round 6: the key must be the table's own scale)
+        f.adopt_packed(table_half, 1.0)
+    f._packed[1.0] = ((id(f.forest_cu), f.forest_cu.version), buf)  # the same memory once more: adopt into the known address
+    f._packed[0.5] = f._packed.pop(1.0)
+    same_buf = f.adopt_packed(table_half, 0.5)
     assert same_buf.ptr == buf.ptr
     scale = __import__("ctypes").c_float(0)
     assert lib.rdf_forest_info(buf.ptr, 3, 10, 4, gpu_runtime.stream(), None, None, __import__("ctypes").byref(scale)) == 0 and scale.value == 0.5
@@ -1523,34 +1624,185 @@ def test_a_table_that_lands_on_a_known_address_is_read_afresh(rdf, oracle, gpu_r
     wild = forest_np.copy()
     wild[0, 0, 0] = 3.0e7
     fw = rdf.DecisionForest.from_numpy(wild)
-    fw.adopt_packed(rdf.DecisionForest.from_numpy(wild).packed_bytes(0.5), 1.0)
+    fw.adopt_packed(rdf.DecisionForest.from_numpy(wild).packed_bytes(0.5), 0.5)
     out.fill(65535)
-    rc = lib.rdf_eval_forest_packed(depth.ptr, 2, 160, 96, fw.packed(1.0).ptr, fw.forest_cu.ptr, 3, 10, 4, None, -1, out.ptr, 1, gpu_runtime.stream())
+    rc = lib.rdf_eval_forest_packed(depth.ptr, 2, 160, 96, fw.packed(0.5).ptr, fw.forest_cu.ptr, 3, 10, 4, None, -1, out.ptr, 1, gpu_runtime.stream())
     want_half = np.full(depth_np.shape, 65535, np.uint16)
     oracle.eval_forest(depth_np, wild, want_half, 1, None, None, 0.5)
     assert rc == 0 and np.array_equal(out.get(), want_half)
 
 
+def test_a_table_copied_over_a_known_address_without_forget_is_reported_stale(rdf, oracle, gpu_runtime):
+    """What a C consumer can do wrong (round 6): write ANOTHER packed table over an address the library has evaluated from --
+    a plain copy, no rdf_forest_pack, no rdf_forest_forget.  Every packing carries a generation number in its info block and
+    every launch the number the host remembers; the kernel compares them and raises the device's stale flag (pinned host
+    memory: no synchronous read), the NEXT call returns RDF_ERR_STALE and the library has forgotten what it knew, the call
+    after that reads the info block afresh.  The launch that met the foreign table already used the TABLE's scale (the kernel
+    reads it from the info block, not from the host's memory), so its labels are the new table's."""
+    import ctypes
+    lib, st = gpu_runtime.lib, gpu_runtime.stream()
+    forest_np = rdf.synth.forest(3, 10, 4, "trained", 5)
+    wild = forest_np.copy()
+    wild[0, 0, 0] = 3.0e7                                           # an exact node at the root of tree 0: the scale matters
+    depth_np = rdf.synth.frames(["dense", "live"], 7100, 96, 160)
+    depth = rdf.to_device(depth_np)
+    out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+    want = {}
+    for s in (1.0, 0.5):
+        want[s] = np.full(depth_np.shape, 65535, np.uint16)
+        oracle.eval_forest(depth_np, wild, want[s], 1, None, None, s)
+    assert not np.array_equal(want[1.0], want[0.5])
+    f = rdf.DecisionForest.from_numpy(wild)
+    buf = f.packed(1.0)
+
+    def call(forest_ptr=f.forest_cu.ptr):
+        out.fill(65535)
+        rc = lib.rdf_eval_forest_packed(depth.ptr, 2, 160, 96, buf.ptr, forest_ptr, 3, 10, 4, None, -1, out.ptr, 1, st)
+        return rc, out.get()                                        # (.get() synchronises: the kernel has run)
+
+    rc, got = call()
+    assert rc == 0 and np.array_equal(got, want[1.0])
+    other = rdf.DecisionForest.from_numpy(wild).packed_bytes(0.5)   # the same forest packed for another scale, elsewhere
+    buf.set(other)                                                  # a raw copy over the known address; the library is not told
+    rc, got = call()
+    assert rc == 0 and np.array_equal(got, want[0.5])               # the table's own scale
+    rc, _ = call()
+    assert rc == -7 and b"rdf_forest_forget" in lib.rdf_error_string(-7)
+    rc, got = call()
+    assert rc == 0 and np.array_equal(got, want[0.5])
+    scale = ctypes.c_float(0)
+    assert lib.rdf_forest_info(buf.ptr, 3, 10, 4, st, None, None, ctypes.byref(scale)) == 0 and scale.value == 0.5
+    # the other thing the host remembers is whether a table needs the caller's forest: a tame table evaluated without one ...
+    tame = rdf.DecisionForest.from_numpy(forest_np)
+    buf.set(tame.packed_bytes(1.0))
+    assert lib.rdf_forest_forget(buf.ptr) == 0                      # (told this time)
+    rc, got = call(None)
+    tame_want = np.full(depth_np.shape, 65535, np.uint16)
+    oracle.eval_forest(depth_np, forest_np, tame_want)
+    assert rc == 0 and np.array_equal(got, tame_want)
+    # ... and the wild one copied over it without a word: no fault (the kernel has no forest to read), the flag, then the refusal
+    buf.set(other)
+    rc, _ = call(None)
+    assert rc == 0
+    rc, _ = call(None)
+    assert rc == -7
+    rc, _ = call(None)
+    assert rc == -2                                                 # RDF_ERR_NULL_PTR: this table needs the forest
+    rc, got = call()
+    assert rc == 0 and np.array_equal(got, want[0.5])
+    f._forget(buf)
+
+
+def test_split_launch_shares_one_tile_queue(rdf, oracle, gpu_runtime):
+    """rdf_eval_forest_packed_split (round 6): a main launch on a CU-masked stream and a helper launch on an ordinary stream
+    pull from ONE tile queue.  Whenever the helper arrives -- at once, a few hundred microseconds into the main launch, after
+    the main launch has finished -- every tile is evaluated exactly once: the oracle's labels, with and without the fused
+    fill, on back-to-back steps that alternate the queue tag, and for a launch too small to split."""
+    import ctypes
+    import torch
+    lib = gpu_runtime.lib
+    forest_np = rdf.synth.forest(4, 12, 4, "trained", 31)
+    depth_np = rdf.synth.mixed_batch(24, 8800, 480, 848)
+    want = np.full(depth_np.shape, 65535, np.uint16)
+    oracle.eval_forest(depth_np, forest_np, want)
+    f = rdf.DecisionForest.from_numpy(forest_np)
+    f.packed(1.0)
+    depth = rdf.to_device(depth_np)
+    ev = rdf.DecisionTreeEvaluator()
+    ev.auto_tune = False
+    h = ctypes.c_void_p()
+    assert lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), 32) == 0
+    main = torch.cuda.ExternalStream(h.value)
+    helper = torch.cuda.Stream()
+    t_start = rdf.DeviceArray((64,), np.uint64).fill(0)
+    outs = [rdf.DeviceArray(depth_np.shape, np.uint16) for _ in range(3)]
+    try:
+        for delay_ticks, fill in ((0, False), (30_000, False), (30_000, True), (3_000_000, False)):     # 0, 0.3 ms, 30 ms
+            out = outs[0].fill(0 if fill else 65535)
+            torch.cuda.synchronize()
+            if delay_ticks:         # something that keeps the helper stream (and the 32 reserved CUs) busy for a while
+                assert lib.rdf_debug_fat_kernel(16, delay_ticks, t_start.ptr, ctypes.c_void_p(helper.cuda_stream)) == 0
+            with torch.cuda.stream(main):
+                n = ev.get_labels_forest_split(f, depth, out, helper.cuda_stream, 32, queue_tag=0, fill_untouched=fill)
+            torch.cuda.synchronize()
+            got = out.get()
+            assert n > 0 and np.array_equal(got, want), (delay_ticks, fill, n, int((got != want).sum()))
+        # three steps back to back, tags alternating, the next step's main launch ordered after the helper of the step before
+        for o in outs:
+            o.fill(65535)
+        torch.cuda.synchronize()
+        for s, o in enumerate(outs):
+            if s == 1:
+                assert lib.rdf_debug_fat_kernel(16, 50_000, t_start.ptr, ctypes.c_void_p(helper.cuda_stream)) == 0
+            with torch.cuda.stream(main):
+                helper.wait_stream(main)
+                ev.get_labels_forest_split(f, depth, o, helper.cuda_stream, 32, queue_tag=s & 1)
+                main.wait_stream(helper)
+        torch.cuda.synchronize()
+        for s, o in enumerate(outs):
+            got = o.get()
+            assert np.array_equal(got, want), (s, int((got != want).sum()))
+        # the same stream's ordinary launches afterwards: the split slots are their own
+        out = outs[0].fill(65535)
+        with torch.cuda.stream(main):
+            ev.get_labels_forest(f, depth, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.get(), want)
+        # one frame: no more tiles than the main launch has workgroups -- not split, the helper stream is not touched
+        one = rdf.DeviceArray((1,) + depth_np.shape[1:], np.uint16).fill(65535)
+        with torch.cuda.stream(main):
+            n = ev.get_labels_forest_split(f, depth[3:4], one, helper.cuda_stream, 32)
+        torch.cuda.synchronize()
+        assert np.array_equal(one.get(), want[3:4])
+        # helper_cus 0, or the same stream twice: one ordinary launch
+        for hs, cus in ((helper.cuda_stream, 0), (main.cuda_stream, 32)):
+            out = outs[1].fill(65535)
+            with torch.cuda.stream(main):
+                assert ev.get_labels_forest_split(f, depth, out, hs, cus) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(out.get(), want)
+    finally:
+        torch.cuda.synchronize()
+        lib.rdf_stream_destroy(h)
+
+
 def test_first_evaluation_of_an_unseen_table_cannot_be_captured(rdf, gpu_runtime):
     """RDF_ERR_CAPTURE, not a generic bad argument: the first evaluation of a table the process has not seen reads its info
-    block back, which a stream under capture cannot do; after one evaluation (or a pack) capture works."""
+    block back, which a stream under capture cannot do; after one look at the table (an evaluation, a pack, rdf_forest_info --
+    which is what adopt_packed does at once since round 6) capture works."""
     import torch
     lib = gpu_runtime.lib
     forest_np = rdf.synth.forest(2, 8, 4, "trained", 3)
     f = rdf.DecisionForest.from_numpy(forest_np)
-    f.adopt_packed(rdf.DecisionForest.from_numpy(forest_np).packed_bytes(1.0), 1.0)
+    table = rdf.DecisionForest.from_numpy(forest_np).packed_bytes(1.0)
+    raw = rdf.DeviceArray((table.size,), np.uint8).set(table)       # a plain upload: the library has not looked at these bytes
     depth = rdf.to_device(rdf.synth.frames(["dense"], 1, 64, 96))
     out = rdf.DeviceArray((1, 64, 96), np.uint16).fill(65535)
     side = torch.cuda.Stream()
-    graph = torch.cuda.CUDAGraph()
-    rcs = []
-    with torch.cuda.graph(graph, stream=side):
-        rcs.append(lib.rdf_eval_forest_packed(depth.ptr, 1, 96, 64, f.packed(1.0).ptr, f.forest_cu.ptr, 2, 8, 4, None, -1, out.ptr, 1,
-                                              gpu_runtime.stream()))
-        out.fill(65535)         # (something to record: an empty capture is an error of its own on some runtimes)
+
+    def captured(ptr):
+        graph = torch.cuda.CUDAGraph()
+        rcs = []
+        with torch.cuda.graph(graph, stream=side):
+            out.fill(65535)         # (also: something to record -- an empty capture is an error of its own on some runtimes)
+            rcs.append(lib.rdf_eval_forest_packed(depth.ptr, 1, 96, 64, ptr, f.forest_cu.ptr, 2, 8, 4, None, -1, out.ptr, 1,
+                                                  gpu_runtime.stream()))
+        return rcs, graph
+
+    rcs, _ = captured(raw.ptr)
     assert rcs == [-6] and b"captured" in lib.rdf_error_string(-6)
-    assert lib.rdf_eval_forest_packed(depth.ptr, 1, 96, 64, f.packed(1.0).ptr, f.forest_cu.ptr, 2, 8, 4, None, -1, out.ptr, 1,
+    assert lib.rdf_eval_forest_packed(depth.ptr, 1, 96, 64, raw.ptr, f.forest_cu.ptr, 2, 8, 4, None, -1, out.ptr, 1,
                                       gpu_runtime.stream()) == 0
+    want = out.get()
+    # an ADOPTED table has been looked at: its very first evaluation can be recorded
+    f.adopt_packed(table, 1.0)
+    rcs, graph = captured(f.packed(1.0).ptr)
+    assert rcs == [0]
+    out.fill(0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.get(), want) and (want != 65535).any()
+    lib.rdf_forest_forget(raw.ptr)
 
 
 def test_deep_blocks_at_config5_size(rdf, evs, oracle, gpu_runtime):
@@ -1643,6 +1895,50 @@ def test_depth_24_forests_walk_their_deep_blocks(rdf, oracle, gpu_runtime, T):
     finally:
         lib.rdf_set_deep_from(-1)
         lib.rdf_set_block_threads(0)
+
+
+@pytest.mark.parametrize("T,D,C", [(2, 25, 4), (1, 27, 4), (1, 28, 2), (1, 30, 1)])
+def test_the_deepest_forests_the_abi_accepts(rdf, oracle, gpu_runtime, T, D, C):
+    """The ABI takes max_depth <= 30, packed tables <= 27, deep blocks <= 24; until round 6 nothing deeper than 24 had run on
+    hardware.  Spine forests (all zeros but one path per tree: no host memory to speak of) at D25 and D27 through the packed
+    tables -- 32-bit byte offsets inside one tree up to 2^31 -- and at D28 and D30 through the reference layout, where the
+    reference's own int32 addressing (cu_utils.hpp:32-39: (idx_offset + node) * els_per_node) has long wrapped and this
+    library's 64-bit addressing has not: the oracle's labels, walks that end on every level down to D - 1."""
+    forest_np, rows = _spine_forest(T, D, C, spine_trees=tuple(range(T)))
+    depth_np = rdf.synth.frames(["dense", "dense", "live"], 4300, 96, 160)
+    want = np.full(depth_np.shape, 65535, np.uint16)
+    st = np.zeros(3, np.uint64)
+    oracle.eval_forest(depth_np, forest_np, want, stats=st)
+    lengths = oracle.walk_lengths(depth_np, forest_np)
+    assert int(lengths.max()) == D and int(st[1]) > 6 * int(st[0])                 # some walk goes all the way down
+    del forest_np
+    f = rdf.DecisionForest(T, D, C)                                  # zeros on the device; the spine nodes one by one
+    for (k, node), row in rows.items():
+        f.forest_cu[k][node].set(row)
+    depth = rdf.to_device(depth_np)
+    ev = rdf.DecisionTreeEvaluator()
+    ev.auto_tune = False
+    lib = gpu_runtime.lib
+    assert (lib.rdf_forest_packed_bytes(T, D, C) > 0) and ((D <= 27) == (f.max_depth <= 27))
+    try:
+        for block in (256, 512):
+            lib.rdf_set_block_threads(block)
+            out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+            ev.get_labels_forest(f, depth, out)                      # packed for D <= 27, the reference layout beyond
+            got = out.get()
+            assert np.array_equal(got, want), (T, D, C, block, int((got != want).sum()))
+        if D <= 27:     # ... and a packed forest's reference-layout evaluation, for the same answer
+            lib.rdf_set_block_threads(0)
+            out = rdf.DeviceArray(depth_np.shape, np.uint16).fill(65535)
+            rdf.DecisionTreeEvaluator(use_packed=False).get_labels_forest(f, depth, out)
+            assert np.array_equal(out.get(), want)
+        else:
+            assert lib.rdf_forest_pack(f.forest_cu.ptr, T, D, C, 1.0, f.forest_cu.ptr, gpu_runtime.stream()) == -1      # RDF_ERR_BAD_ARG: packed tables stop at 27
+    finally:
+        lib.rdf_set_block_threads(0)
+    del f
+    import torch
+    torch.cuda.empty_cache()
 
 
 def test_deep_blocks_fuzz(rdf, evs, oracle, gpu_runtime):

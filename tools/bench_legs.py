@@ -225,7 +225,7 @@ def train(rdf, images=64, depth=12, proposals=256, blocks=1, noisy_labels=False,
     return out
 
 
-def trainer_forest(rdf, frames_np, trees=4, depth=20, images=64, proposals=512, train_frames=None):
+def trainer_forest(rdf, frames_np, trees=4, depth=20, images=64, proposals=512, train_frames=None, return_forest=False):
     """A forest produced by THIS repo's trainer (DecisionTreeTrainer) instead of a synthetic topology: `trees` trees of depth
     `depth` trained on `images` frames of the bench's mix labelled by a teacher (a balanced tree's labels: something a deep
     tree can fit), evaluated on the headline's batch `frames_np`: nodes the trainer wrote and the batch visits per level, the
@@ -285,7 +285,7 @@ def trainer_forest(rdf, frames_np, trees=4, depth=20, images=64, proposals=512, 
     visited = rdf_oracle.distinct_nodes_per_level(frames_np[0:min(8, n)], forest_np).sum(axis=0)
     lv = rdf_oracle.walk_lengths(frames_np[0:min(8, n)], forest_np)
     valid = lv.max(axis=3) > 0
-    return {"value": round(n * h * w / ms / 1e3, 2), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "frames": n,
+    res = {"value": round(n * h * w / ms / 1e3, 2), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "frames": n,
             "forest": f"T{trees}/D{depth}/C{C} trained by DecisionTreeTrainer on {images} teacher-labelled frames, {proposals} proposals per level",
             "train_seconds_per_tree": train_s, "nodes_written_per_level": written,
             "nodes_visited_per_level_by_8_frames": [int(v) for v in visited],
@@ -293,3 +293,4 @@ def trainer_forest(rdf, frames_np, trees=4, depth=20, images=64, proposals=512, 
             "levels_per_pixel_and_tree": round(float(lv[valid].mean()), 2), "tune": tune,
             "parity": {"frames_checked": ns, "differing_pixels": mism, "checker": "oracle/rdf_oracle.c on the host"},
             "setup_seconds": round(time.perf_counter() - t0, 1)}
+    return (res, forest_np) if return_forest else res

@@ -68,6 +68,59 @@ def main():
         if h is not None:
             torch.cuda.synchronize()
             lib.rdf_stream_destroy(h)
+    # ---- split steps (round 6): the gather of step s-1 occupies the 32 reserved CUs for the FIRST part of step s, then they
+    # idle.  Main launch on the masked stream at once; the stand-in (RCCL's footprint, spinning for `ms`) on a side stream at
+    # the same time; a helper launch that waits for the stand-in and then pulls tiles from the main launch's queue
+    # (rdf_eval_forest_packed_split).  Compared with the masked stream alone and with all 256 CUs and no stand-in at all.
+    h = ctypes.c_void_p()
+    assert lib.rdf_stream_create_with_reserved_cus(ctypes.byref(h), 32) == 0
+    main_stream = torch.cuda.ExternalStream(h.value)
+    helper = torch.cuda.Stream()
+    plain = torch.cuda.Stream()
+
+    def timed(fn, reps=7):
+        res = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            fn(e0, e1)
+            torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1))
+        return round(float(np.median(res[2:])), 3)
+
+    def alone(e0, e1):
+        with torch.cuda.stream(plain):
+            e0.record()
+            ev.get_labels_forest(forest, depth, labels)
+            e1.record()
+
+    split = {"all 256 CUs, nothing beside it": timed(alone)}
+    for ms in (0.5, 1.0, 2.0, 3.0):
+        ticks = int(ms * 100_000)
+
+        def masked_only(e0, e1, ticks=ticks):
+            with torch.cuda.stream(side):
+                assert lib.rdf_debug_fat_kernel(16, ticks, t_start.ptr, rt.stream()) == 0
+            with torch.cuda.stream(main_stream):
+                e0.record()
+                ev.get_labels_forest(forest, depth, labels)
+                e1.record()
+
+        def split_step(e0, e1, ticks=ticks):
+            with torch.cuda.stream(side):
+                assert lib.rdf_debug_fat_kernel(16, ticks, t_start.ptr, rt.stream()) == 0
+            helper.wait_stream(side)            # the helper starts when the stand-in has left the reserved CUs
+            with torch.cuda.stream(main_stream):
+                e0.record()
+                ev.get_labels_forest_split(forest, depth, labels, helper.cuda_stream, 32)
+                main_stream.wait_stream(helper)
+                e1.record()
+
+        split[f"stand-in for {ms} ms"] = {"masked stream alone (224 CUs)": timed(masked_only), "split step (224 CUs + helper on 32)": timed(split_step)}
+    out["split step: forest step (ms) next to an RCCL-sized stand-in that holds the 32 reserved CUs from the start of the step"] = split
+    torch.cuda.synchronize()
+    lib.rdf_stream_destroy(h)
+
     # the peer-copy gather's data movement: a 104-MB device-to-device hipMemcpyAsync on a side stream, 1 ms into a
     # forest launch on an ordinary stream (on this one-GPU box the copy stays on the device; between GPUs it is the
     # copy engines' job)
