@@ -201,6 +201,7 @@ struct EvalArgs {
     uint32_t fold;         // 0: no narrow tiles; 2 or 4
     uint32_t tiles_y_n;
     int tw_n, th_n, twp_n;
+    int halo_xn;           // their halo in x (<= halo): chosen so that the `fold` rows of a wave do not share LDS banks
     uint32_t stage_tw8_n, stage_magic_n;
     uint32_t tiles_y;      // ceil(Hl / (waves per block * rows_per_wave))
     int rows_per_wave;     // 1..kMaxRowsPerWave
@@ -406,15 +407,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
     const int lane = tid & 63;
     const int K = a.lds_levels;
     const uint32_t nodes_lds = (1u << K) - 1u;
-    // (round 6) the table's own words, not the host's memory of them: the scale its numerators were packed for (kFlagExact
-    // nodes recompute theirs with it) and the generation of the packing.  A table that is not the one the host remembers at
-    // this address raises the stale flag; the library then forgets what it knew and the next call says RDF_ERR_STALE.
-    float s_exact = a.s;
-    if (PACKED && a.info) {
-        s_exact = a.info->scale;
-        if (a.info->generation != a.expect_gen && a.stale_flag && blockIdx.x == 0 && tid == 0)
-            __hip_atomic_store(a.stale_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    // (round 6) the table's own words, not the host's memory of them, read where they are needed and nowhere near the
+    // prologue (a load in front of the first tile cost a one-frame launch 3 us): the scale inside the rare kFlagExact branch,
+    // the generation in the epilogue of workgroup 0.
     constexpr uint32_t kWaves = BLOCK / 64;
     const int rows_per_wave = a.rows_per_wave;
     const uint32_t wave = (uint32_t)tid >> 6;
@@ -557,7 +552,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
         const uint32_t img_boff = (img * a.per_img_d) << 1;
         const uint32_t img_loff = img * a.per_img_l;
         // depth coordinates of the staged tile's first cell
-        const int tx0 = (int)x0 * a.r - a.halo;
+        const int tx0 = (int)x0 * a.r - (narrow ? a.halo_xn : a.halo);
         const int ty0 = (int)y0 * a.r - a.halo;
         const int tw = narrow ? a.tw_n : a.tw, th = narrow ? a.th_n : a.th, twp = narrow ? a.twp_n : a.twp;
         const uint32_t stage_tw8 = narrow ? a.stage_tw8_n : a.stage_tw8, stage_magic = narrow ? a.stage_magic_n : a.stage_magic;
@@ -865,6 +860,7 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
                                             // (packed tables too: the numerators are recomputed from the caller's forest with the
                                             // scale the table was packed for -- read from the table's own info block -- one
                                             // multiply, as rdf_forest_pack did)
+                                            const float s_exact = (PACKED && a.info) ? a.info->scale : a.s;
                                             const float *p = a.forest +
                                                 ((size_t)tk * (size_t)a.nodes + (hn[k] - 1u)) * (size_t)a.E;
                                             n[k].ax = s_exact * p[0]; n[k].ay = s_exact * p[1];
@@ -1230,6 +1226,14 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
                 }
             }
         }
+    }
+
+    // ---- (round 6) is the table the one the host remembers at this address?  Every packing carries a generation; a launch
+    // that finds another one raises the device's stale flag (pinned host memory): the library then forgets what it knew and
+    // the next call says RDF_ERR_STALE ----
+    if (PACKED && a.info && a.stale_flag && blockIdx.x == 0 && tid == 0 && !a.q_helper) {
+        if (a.info->generation != a.expect_gen)
+            __hip_atomic_store(a.stale_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
     // ---- queue epilogue: the last workgroup to finish puts the slot back to zero (every
@@ -1766,9 +1770,9 @@ int launch_multi(const EvalArgsN<NL> &ka, int lds_bytes, int cus, hipStream_t st
     return (int)hipGetLastError();
 }
 
-// Which instantiations exist (69 kernels; every one costs half a second of compile time and ~20 KB of code object, so the list is
+// Which instantiations exist (65 kernels; every one costs half a second of compile time and ~20 KB of code object, so the list is
 // what launches really take -- rows per wave, halo, LDS levels, scheduler are run-time arguments):
-//   packed table, no pixel list:         256 / 512 threads x 4 / 8 / 16 classes in registers x 1 / 2 / 3 / 4 trees in a lane
+//   packed table, no pixel list:         256 / 512 threads x 4 / 8 classes in registers x 1 / 2 / 3 / 4 trees in a lane, 16 classes x 1 / 4 trees
 //   packed table, filtered (pixel list): 256 / 512 threads x 4 / 8 / 16 classes x 4 trees in a lane
 //   reference-layout forest:             256 / 512 threads x 4 / 16 classes x 1 or 4 trees in a lane (a filtered launch
 //                                        takes the early-outs per lane instead of listing pixels)
@@ -1792,12 +1796,13 @@ int launch_group(bool compact, const EvalArgs &a, int lds_bytes, int cus, hipStr
     const int g = group_for(a, PACKED);
     if constexpr (PACKED) {
         if (compact) return launch_one<BLOCK, true, CMAX, false, 4, true>(a, lds_bytes, cus, st);
-        switch (g) {
-        case 1: return launch_one<BLOCK, true, CMAX, false, 1, false>(a, lds_bytes, cus, st);
-        case 2: return launch_one<BLOCK, true, CMAX, false, 2, false>(a, lds_bytes, cus, st);
-        case 3: return launch_one<BLOCK, true, CMAX, false, 3, false>(a, lds_bytes, cus, st);
-        default: return launch_one<BLOCK, true, CMAX, false, 4, false>(a, lds_bytes, cus, st);
+        if constexpr (CMAX <= 8) {      // (forests of more than eight classes: one or four trees in a lane only -- round 6 took the two- and
+                                        // three-wide sixteen-class kernels out to pay for the narrow tiles' code: slots beyond the last tree idle)
+            if (g == 2) return launch_one<BLOCK, true, CMAX, false, 2, false>(a, lds_bytes, cus, st);
+            if (g == 3) return launch_one<BLOCK, true, CMAX, false, 3, false>(a, lds_bytes, cus, st);
         }
+        if (g == 1) return launch_one<BLOCK, true, CMAX, false, 1, false>(a, lds_bytes, cus, st);
+        return launch_one<BLOCK, true, CMAX, false, 4, false>(a, lds_bytes, cus, st);
     } else {
         return g == 1 ? launch_one<BLOCK, false, CMAX, false, 1, false>(a, lds_bytes, cus, st)
                       : launch_one<BLOCK, false, CMAX, false, 4, false>(a, lds_bytes, cus, st);
@@ -2282,19 +2287,35 @@ int eval_common(const uint16_t *depth, int n_img, int dim_x, int dim_y, const vo
         if (vec && (twp * 2) % 512 == 0) twp += 8;          // not a whole number of LDS bank sweeps per row
         long long bytes = (th * twp * 2 + 15) & ~15ll;
         // (narrow tiles: 64 / fold columns x fold x tile_rows rows of centres, the same halo; the allocation holds either shape)
-        long long tw_n = 0, th_n = 0, twp_n = 0;
+        long long tw_n = 0, th_n = 0, twp_n = 0, hx_n = h;
         if (a.fold) {
-            tw_n = (64ll / a.fold - 1) * r + 1 + 2ll * h;
+            // A wave of a narrow tile reads `fold` rows of the staged tile at once: with a row pitch of a whole number of LDS bank
+            // sweeps (256 bytes: 16 columns + 2 x 56 of halo) the rows fall into the SAME banks -- a four-way conflict on every probe
+            // (measured: the narrow tiles gave 2 % where their 5 % fewer wave-rows promised more).  The pitch modulo 256 bytes must
+            // leave room for one row segment on either side: padding when it fits the budget, else a few columns less halo in x.
             th_n = ((long long)tile_rows * a.fold - 1) * r + 1 + 2ll * h;
-            if (vec) tw_n = (tw_n + 7) & ~7ll;
-            twp_n = vec ? tw_n : (tw_n + 1) & ~1ll;
-            if (vec && (twp_n * 2) % 512 == 0) twp_n += 8;
+            const long long seg = (64ll / a.fold) * 2 * r;          // bytes one row of a wave spans
+            auto shape = [&](long long hx, long long pad) {
+                tw_n = (64ll / a.fold - 1) * r + 1 + 2ll * hx;
+                if (vec) tw_n = (tw_n + 7) & ~7ll;
+                twp_n = (vec ? tw_n : (tw_n + 1) & ~1ll) + pad;
+                const long long m = (twp_n * 2) % 256;
+                return seg > 128 || (m >= seg && m <= 256 - seg);
+            };
+            bool ok_banks = shape(h, 0);
+            for (long long pad = 8; !ok_banks && pad <= 64; pad += 8)
+                ok_banks = shape(h, pad) && ((th_n * twp_n * 2 + 15) & ~15ll) <= std::max(bytes, (long long)0) ;   // (padding that costs no halo)
+            for (long long hx = h - (vec ? 8 : 2); !ok_banks && hx >= 0 && hx >= h - 24; hx -= (vec ? 8 : 2)) {
+                ok_banks = shape(hx, 0);
+                if (ok_banks) hx_n = hx;
+            }
+            if (!ok_banks) { hx_n = h; (void)shape(h, 0); }
             bytes = std::max(bytes, (th_n * twp_n * 2 + 15) & ~15ll);
         }
         if (bytes <= tile_budget) {
             tile_bytes = bytes;
             a.halo = h; a.tw = (int)tw; a.th = (int)th; a.twp = (int)twp;
-            a.tw_n = (int)tw_n; a.th_n = (int)th_n; a.twp_n = (int)twp_n;
+            a.tw_n = (int)tw_n; a.th_n = (int)th_n; a.twp_n = (int)twp_n; a.halo_xn = (int)hx_n;
             if (vec) {
                 a.stage_tw8 = (uint32_t)(tw >> 3);
                 a.stage_magic = (uint32_t)((1ull << 32) / a.stage_tw8) + 1u;

@@ -40,12 +40,14 @@ def edit():
     t = open(p).read()
     # -- bigger workgroups
     t = sub1(t, "__launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : 4)",
-             "__launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : BLOCK == 768 ? 6 : 4)")
+             "__launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK == 256 ? 5 : BLOCK == 768 ? 6 : BLOCK == 896 ? 7 : BLOCK == 1024 ? RDF_EXP_WAVES_1024 : 4)")
+    t = sub1(t, "namespace {\n\nconstexpr int kGroup = 4;", "#ifndef RDF_EXP_WAVES_1024\n#define RDF_EXP_WAVES_1024 4\n#endif\nnamespace {\n\nconstexpr int kGroup = 4;")
     t = sub1(t, "if (block != 256 && block != 512) block = (big && !filtered_r1) ? 512 : 256;",
-             "if (block != 256 && block != 512 && block != 768 && block != 1024) block = (big && !filtered_r1) ? 512 : 256;\n"
-             "    if ((block == 768 || block == 1024) && (!packed || filter_class != -1 || n_classes > 4 || stats)) block = 512;")
+             "if (block != 256 && block != 512 && block != 768 && block != 896 && block != 1024) block = (big && !filtered_r1) ? 512 : 256;\n"
+             "    if (block > 512 && (!packed || filter_class != -1 || n_classes > 4 || stats)) block = 512;")
     t = sub1(t, "        rc = block == 512 ? launch_block<512>(packed != nullptr, compact_launch, a, lds_bytes, cus, st)\n",
              "        rc = block == 768 ? launch_one<768, true, 4, false, 4, false>(a, lds_bytes, cus, st)\n"
+             "           : block == 896 ? launch_one<896, true, 4, false, 4, false>(a, lds_bytes, cus, st)\n"
              "           : block == 1024 ? launch_one<1024, true, 4, false, 4, false>(a, lds_bytes, cus, st)\n"
              "           : block == 512 ? launch_block<512>(packed != nullptr, compact_launch, a, lds_bytes, cus, st)\n")
     # (rows per wave for the big blocks: the knob; default 2)
@@ -71,7 +73,7 @@ def edit():
              "#else\n"
              "                                n[k] = decode_node(lds_nodes[tk * lds_pitch + hn[k]]);\n"
              "#endif\n")
-    t = sub1(t, "        if (a.stage_tw8 > 0u) {\n", "#ifdef RDF_ABL_STAGE\n        if (false) {\n#else\n        if (a.stage_tw8 > 0u) {\n#endif\n")
+    t = sub1(t, "        if (stage_tw8 > 0u) {\n", "#ifdef RDF_ABL_STAGE\n        if (false) {\n#else\n        if (stage_tw8 > 0u) {\n#endif\n")
     open(p, "w").write(t)
     d = os.path.join(SRC, "rdf_device.hpp")
     t = open(d).read()
@@ -86,7 +88,7 @@ def edit():
     open(d, "w").write(t)
 
 
-VARIANTS = {"base": [], "pdf": ["-DRDF_ABL_PDF"], "lds9": ["-DRDF_ABL_LDSNODES=9"], "lds11": ["-DRDF_ABL_LDSNODES=11"],
+VARIANTS = {"base": [], "w8": ["-DRDF_EXP_WAVES_1024=8"], "pdf": ["-DRDF_ABL_PDF"], "lds9": ["-DRDF_ABL_LDSNODES=9"], "lds11": ["-DRDF_ABL_LDSNODES=11"],
             "stage": ["-DRDF_ABL_STAGE"], "far": ["-DRDF_ABL_FAR"]}
 
 
