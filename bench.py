@@ -168,7 +168,7 @@ def cached(name, make):
     return arr
 
 
-COMMITTED_COUNTERS = ("r05_roofline_counters.json", "r04_roofline_counters.json")     # newest first
+COMMITTED_COUNTERS = ("r06_roofline_counters.json", "r05_roofline_counters.json", "r04_roofline_counters.json")     # newest first
 
 
 def committed_counters(key):

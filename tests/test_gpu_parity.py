@@ -133,6 +133,48 @@ def test_layered_run_on_gpu_matches_golden(rdf, gpu_runtime, tmp_path):
     assert lf.eval.composite_bad_pixels() == 0
 
 
+@pytest.mark.parametrize("kind", ["live", "dense"])
+def test_config3_full_size_plain_layered_run(kind, rdf, gpu_runtime, oracle):
+    """BASELINE configs[2] at its full size through the plain drop-in call: LayeredDecisionForest.run on one
+    848x480 frame, labels_reduce 2, scale 848/848, a 2-layer stack whose second layer filters on the first one's class 3
+    (run_live_layered.py:54, 126) -- the fused one-call route (layers in one launch, a wave per tree), the same with those
+    two switched off, and the reference's step-by-step sequence: every per-layer label image and the composite are the
+    oracle's.  (tests/test_pipeline.py reaches this size only through HandPipeline.)"""
+    lib = gpu_runtime.lib
+    synth = rdf.synth
+    f0, f1 = synth.forest(3, 12, 4, "trained", 80), synth.forest(4, 14, 4, "trained", 90)
+    cond = [[0, 1], [0, 2], [1, 3], [0, 3], [0, 4], [0, 5]]          # layer 0: 1, 2 final, 3 -> layer 1 (decision_tree.py:214-220)
+    cfg = {"layers": [{"model": rdf.DecisionForest.from_numpy(f0)},
+                      {"model": rdf.DecisionForest.from_numpy(f1), "filter_model": 0, "filter_model_class": 3}],
+           "conditions": cond, "label_colors": [[9, 8, 7, 255]] * 5}
+    H, W, R = 480, 848, 2
+    frame = synth.frames([kind], 4100, H, W)
+    l0 = np.full((1, H // R, W // R), 65535, np.uint16)
+    l1, comp = l0.copy(), l0.copy()
+    oracle.eval_forest(frame, f0, l0, R, None, None, 1.0)
+    oracle.eval_forest(frame, f1, l1, R, l0, 3, 1.0)
+    oracle.composite([l0[0], l1[0]], np.array(cond, np.int32), comp)
+    assert (l1 != 65535).any() and len(np.unique(comp)) >= 4
+    lf = rdf.LayeredDecisionForest(cfg, (H, W), R)
+    depth, labels = rdf.GpuBuffer((H, W), np.uint16), rdf.GpuBuffer((H // R, W // R), np.uint16)
+    depth.cu().set(frame[0])
+    try:
+        for fused, one_launch, tw in ((True, -1, -1), (True, 0, 0), (False, -1, -1), (True, -1, 0)):
+            lf.fused = fused
+            lib.rdf_set_layers_one_launch(one_launch)
+            lib.rdf_set_tree_waves(tw)
+            labels.cu().fill(4242)
+            lf.run(depth, labels, 848 / 848)
+            what = (fused, one_launch, tw)
+            assert np.array_equal(lf.label_images[0].cu().get(), l0[0]), what
+            assert np.array_equal(lf.label_images[1].cu().get(), l1[0]), what
+            assert np.array_equal(labels.cu().get(), comp[0]), what
+        assert lf.eval.composite_bad_pixels() == 0
+    finally:
+        lib.rdf_set_layers_one_launch(-1)
+        lib.rdf_set_tree_waves(-1)
+
+
 SWEEP = [
     # T, D, C, topo, n, h, w, r, s, filter
     (1, 5, 2, "trained", 1, 17, 23, 1, 1.0, False),

@@ -27,13 +27,15 @@ def main(path, tag, line_path=None):
     for leg, r in (("headline", d.get("roofline")), ("cfg2", d.get("cfg2_single_frame", {}).get("roofline")),
                    ("cfg5", d.get("cfg5_shard", {}).get("roofline")),
                    ("headline_balanced", (d.get("cfg2_balanced", {}).get("batch") or {}).get("roofline")),
-                   ("cfg5_balanced", d.get("cfg5_balanced", {}).get("roofline"))):
+                   ("cfg5_balanced", d.get("cfg5_balanced", {}).get("roofline")),
+                   ("headline_trainer", d.get("cfg2_trainer_forest", {}).get("roofline"))):
         if not r or not r.get("counters") or "child passes" not in (r.get("counters_source") or ""):
             continue
         key = {"headline": keys["roofline"], "cfg2": keys["roofline"].replace(f"F{c['frames_per_gpu']}_", "F1_"),
                "cfg5": "F32_T8_D22_C4_full_1280x720",
                "headline_balanced": keys["roofline"].replace(f"_{c['topology']}", "_balanced"),
-               "cfg5_balanced": "F32_T8_D22_C4_balanced_1280x720"}[leg]
+               "cfg5_balanced": "F32_T8_D22_C4_balanced_1280x720",
+               "headline_trainer": keys["roofline"].replace(f"_{c['topology']}", "_trainer")}[leg]
         out[key] = {"kernel": r["kernel"], "counters": r["counters"], "kernel_ms_of_that_run": r["kernel_ms"],
                     "collected_by": f"bench.py's rocprofv3 --pmc child passes ({tag})"}
     if out:
