@@ -1,5 +1,5 @@
-"""The documents quote the committed profiles, not other runs: DESIGN.md's round-5 measurement table is generated from
-profiles/r05_bench.json (tools/design_measurements.py) and must be identical to what the generator prints now; the round's
+"""The documents quote the committed profiles, not other runs: DESIGN.md's round-6 measurement table is generated from
+profiles/r06_bench.json (tools/design_measurements.py) and must be identical to what the generator prints now; the round's
 profiles describe the shipped code (no type that was deleted, no experiment switch left in the product source)."""
 import glob
 import importlib.util
@@ -24,22 +24,22 @@ def test_design_quotes_the_committed_profile():
     have = text[text.index(g.BEGIN):text.index(g.END) + len(g.END)]
     assert have == g.block(), "DESIGN.md section 5 is stale: python3 tools/design_measurements.py --write"
     # ... and the headline figures in it are the compact line's (what the driver parses)
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")).read())
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_line.json")).read())
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
     assert len(json.dumps(line)) < 4096 and line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
     assert f"**{full['value']} Mpix/s**" in have and str(full["cfg5_balanced"]["value"]) in have and str(full["value_balanced"]) in have
     assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
 
 
-def test_round_five_profiles_describe_the_shipped_code():
-    names = glob.glob(os.path.join(ROOT, "profiles", "r05_*"))
+def test_the_rounds_profiles_describe_the_shipped_code():
+    names = glob.glob(os.path.join(ROOT, "profiles", "r06_*"))
     assert names
     for path in names:
         if path.endswith(".patch"):
             continue
         assert "NodeRec32" not in open(path, errors="replace").read(), path      # (a type round 4 deleted after its trace was taken)
     # the kernel signatures in the round's traces are instantiations the shipped source has: nine template arguments
-    for path in glob.glob(os.path.join(ROOT, "profiles", "r05_kernel_stats*.csv")):
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r06_kernel_stats*.csv")):
         for sig in re.findall(r"k_eval_forest<([^>]*)>", open(path).read()):
             assert len(sig.split(",")) == 9, (path, sig)
     for dirpath, _, files in os.walk(os.path.join(ROOT, "3d-beats_amd")):

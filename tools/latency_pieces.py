@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""scratch: pieces of a two-launch single frame (rows 0..383 four trees per lane, rows 384..479 a wave per tree)"""
+"""What one 848x480 frame costs in pieces (round 6): whole, the rows that are exactly ONE round of workgroups (384 with narrow
+tiles), the rows a wave-per-tree launch would take, and the two launched back to back -- with narrow tiles on and off.
+profiles/r06_latency_pieces.txt"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
