@@ -96,7 +96,7 @@ def block():
     row("a forest from the repo's own trainer (T4/D20) on the bench batch",
         f"{tf['value']} Mpix/s, {tf['ms_per_step']} ms; tuned: {tf['tune']['deep_from']} ({tf['tune']['tried']}); its own counter passes (round 6): bound {tfr.get('bound')} {tfr.get('frac')}, "
         f"VALU {(tfl.get('valu') or {}).get('frac')}, L2→L1 {(tfl.get('l2_l1') or {}).get('frac')}, fabric side {(tfl.get('hbm') or {}).get('frac')} of 8 TB/s, L2 hit rate {tfr.get('l2_hit_rate')} — no level near its limit: "
-        f"a chain of dependent fetches whose deep ones miss the L2 ({tf['share_of_level_visited'][-1]:.0%} of level 19 visited: a 24-MB working set)", "`cfg2_trainer_forest`")
+        f"between the cache-resident \"full\" topology and the occupied one ({tf['share_of_level_visited'][-1]:.0%} of level 19 visited, a 24-MB working set of hot records), it pays the walk's dependent chain with L2 latencies in it", "`cfg2_trainer_forest`")
     row("frames from and labels to HOST memory", f"serial {d['pcie_inclusive']['value']} Mpix/s; `HostFramesEvaluator` {d['pcie_inclusive_pipelined']['value']} Mpix/s ({d['pcie_inclusive_pipelined']['ms_per_step']} ms per step)",
         "`pcie_inclusive`, `pcie_inclusive_pipelined`")
     row("other legs", f"reference-layout forest {d['unpacked']['value']} Mpix/s; trained-like batch {d['cfg2_trained']['batch']['value']} Mpix/s; per-hand chain as one hipGraph {d['hand_pipeline']['us_per_hand_per_frame_as_hipgraph']} µs; "
