@@ -142,6 +142,31 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_line(gather, tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_ranks_with_split_steps(tmp_path):
+    """Round 6: the RCCL mode's steps are split launches (main launch on the CU-masked stream, helper launch behind the previous
+    step's gather, one tile queue).  Two ranks on the one GPU, each with its own masked stream and helper stream, gloo standing
+    in for RCCL (its wait blocks the host instead of the stream: the ordering is the same): the label maps arrive intact, the
+    line says how many workgroups the helper got, and --no-split-step gives the same maps from one launch per step."""
+    for extra, split in (([], True), (["--no-split-step"], False)):
+        env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+               "--frames", "16", "--depth", "12", "--backend", "gloo", "--gather", "rccl", "--reserve-cus", "32", "--no-cfg5",
+               "--full-json", str(tmp_path / "full.json")] + extra
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        c = _last_json(r.stdout)
+        _check_contract(c)
+        m = c["distributed"]["gather_modes"]["rccl gather"]
+        assert c["config"]["gather"] == "rccl gather" and c["config"]["gather_check"] == "ok" and m["cus_left_to_rccl"] == 32
+        assert c["distributed"]["unavailable"] == {}
+        if split:
+            assert m["split_step_helper_workgroups"] > 0, m
+        else:
+            assert "split_step_helper_workgroups" not in m
+
+
+@pytest.mark.gpu
 def test_four_ranks_on_one_gpu(tmp_path):
     """The same rehearsal with four ranks (rank-indexed buffers, checksums and the config-5 leg beyond world size 2; four
     processes on the card stay inside the box's limit of six)."""
