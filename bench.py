@@ -252,7 +252,7 @@ def compact_line(out, full_path=None):
     cfg = out.get("config") or {}
     line["config"] = {"workload": str(cfg.get("workload"))[:260]}
     for k in ("frames_per_gpu", "frame", "trees", "tree_depth", "classes", "topology", "forest_layout", "tile_schedule",
-              "pipeline_chunks", "sharding", "gather", "gather_overlap", "gather_check", "cus_left_to_rccl"):
+              "pipeline_chunks", "sharding", "gather", "gather_overlap", "gather_check", "cus_left_to_rccl", "library_build_id"):
         if cfg.get(k) is not None:
             line["config"][k] = cfg[k]
     line["config"]["deep_from"] = g(cfg, "deep_level_table", "deep_from")
@@ -1005,7 +1005,9 @@ def main():
                    "gather": gather_mode,
                    "gather_overlap": ("next step" if (overlapped or peer is not None) else ("in-step chunks" if multi else None)),
                    "sharding": f"frames x{world}, forest replicated", "gather_check": results[primary]["gather_check"],
-                   "deep_level_table": tune},
+                   "deep_level_table": tune,
+                   # which kernels these numbers are of: the id baked into librdf_hip.so (a hash of its sources and flags)
+                   "library_build_id": (lambda b: b.decode() if isinstance(b, bytes) else str(b))(lib.rdf_build_id())},
         # the same rate counted over the pixels the forest really evaluates (this rank's batch: half of it is live-like
         # frames, 85 % background); the metric counts every depth pixel
         "value_valid_pixels": round(out_value_tmp * valid_px / (F * H * W), 2),
