@@ -1796,6 +1796,20 @@ def test_split_launch_shares_one_tile_queue(rdf, oracle, gpu_runtime):
             n = ev.get_labels_forest_split(f, depth[3:4], one, helper.cuda_stream, 32)
         torch.cuda.synchronize()
         assert np.array_equal(one.get(), want[3:4])
+        # a filtered launch through the C entry point (pixel lists; at labels_reduce 2 such a launch takes 512-thread workgroups)
+        lh, lw = 480 // 2, 848 // 2
+        filt_np = (np.arange(24 * lh * lw).reshape(24, lh, lw) % 3).astype(np.uint16)
+        want_f = np.full((24, lh, lw), 65535, np.uint16)
+        oracle.eval_forest(depth_np, forest_np, want_f, 2, filt_np, 1)
+        filt = rdf.to_device(filt_np)
+        out_f = rdf.DeviceArray((24, lh, lw), np.uint16).fill(0)
+        n_h = ctypes.c_int(0)
+        with torch.cuda.stream(main):
+            rc = lib.rdf_eval_forest_packed_split(depth.ptr, 24, 848, 480, f.packed(1.0).ptr, f.forest_cu.ptr, 4, 12, 4, filt.ptr, 1, out_f.ptr, 2, 1,
+                                                  ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(helper.cuda_stream), 32, 1, ctypes.byref(n_h))
+        torch.cuda.synchronize()
+        got = out_f.get()
+        assert rc == 0 and np.array_equal(got, want_f), (rc, n_h.value, int((got != want_f).sum()))
         # helper_cus 0, or the same stream twice: one ordinary launch
         for hs, cus in ((helper.cuda_stream, 0), (main.cuda_stream, 32)):
             out = outs[1].fill(65535)
