@@ -371,8 +371,10 @@ struct EvalArgsN {
 //                         launches) | DEEP walk the deep levels from the deep blocks
 //   per workgroup, once   "stage the top K levels": the node table's top levels into LDS; which tables serve the forest
 //                         (last-level table, deep blocks: their trailers)
-//   per tile              "take the next tile" (static first tile, then the per-XCD queues) -> "empty tile?" -> "stage depth" into
-//                         LDS at address 0 -> "compact" (COMPACT only)
+//   per tile              "take the next tile" (static first tile, then the per-XCD queues; a helper launch's workgroups have no
+//                         static tile: rdf_eval_forest_packed_split) -> which pixels the lanes of a wave stand on (one row of 64, or
+//                         -- narrow tiles for a label map's last columns -- `fold` rows of 64 / fold) -> "empty tile?" -> "stage
+//                         depth" into LDS at address 0 -> "compact" (COMPACT only)
 //   per pixel group       early-outs (tree_eval.cu:81-89; DEEP: a lane without a pixel stays in the loop with idle tree slots, `live`,
 //                         because the wave fetches its deep blocks together), the pixel's reciprocal, then per CMAX classes and per GROUP trees:
 //       the level loop    round-down mode; node fetch (LDS / packed table / reference records) -> probe coordinates (one fma per
@@ -383,7 +385,7 @@ struct EvalArgsN {
 //                         the general leaf fetch (PDF rows, in tree order)
 //       argmax (tree_eval.cu:7-21) and the label store
 //   TW only               "the T waves of a pixel row hand their trees' results to the row's first wave"
-//   epilogue              queue slot back to zero; STATS reduction
+//   epilogue              (last workgroup) the table's generation against the host's (PackInfo.generation); queue slot back to zero; STATS reduction
 // Bit-exactness rests on three things the sections keep apart: the order of the PDF adds (tree order, round-to-nearest), the
 // mode the fmas run in (round-down, between set_round_down / set_round_nearest: tools/check_rounding_isa.py), and the per-axis
 // bounds of the probes (TileCtx).
@@ -408,8 +410,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
     const int K = a.lds_levels;
     const uint32_t nodes_lds = (1u << K) - 1u;
     // (round 6) the table's own words, not the host's memory of them, read where they are needed and nowhere near the
-    // prologue (a load in front of the first tile cost a one-frame launch 3 us): the scale inside the rare kFlagExact branch,
-    // the generation in the epilogue of workgroup 0.
+    // prologue (a load in front of the first tile is a round trip beyond the L2 that every workgroup of a one-frame launch
+    // would wait for): the scale inside the rare kFlagExact branch, the generation in the epilogue of the launch's last workgroup (asked by
+    // workgroup 0 it cost the smallest launches 0.4 us, measured with the check compiled out).
     constexpr uint32_t kWaves = BLOCK / 64;
     const int rows_per_wave = a.rows_per_wave;
     const uint32_t wave = (uint32_t)tid >> 6;
@@ -1231,7 +1234,9 @@ __global__ __launch_bounds__(BLOCK, TW ? 8 : DEEP ? 4 : BLOCK == 512 ? 6 : BLOCK
     // ---- (round 6) is the table the one the host remembers at this address?  Every packing carries a generation; a launch
     // that finds another one raises the device's stale flag (pinned host memory): the library then forgets what it knew and
     // the next call says RDF_ERR_STALE ----
-    if (PACKED && a.info && a.stale_flag && blockIdx.x == 0 && tid == 0 && !a.q_helper) {
+    // (the LAST workgroup of the launch -- of every role of a multi-layer launch -- asks: its tile is a frame's bottom-right
+    // corner, often partial or empty, so the load's round trip tends to end before the launch's other workgroups do)
+    if (PACKED && a.info && a.stale_flag && block_id == n_blocks - 1u && tid == 0 && !a.q_helper) {
         if (a.info->generation != a.expect_gen)
             __hip_atomic_store(a.stale_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
