@@ -293,3 +293,22 @@ def test_compact_line_of_a_full_result_stays_under_four_kilobytes():
     assert c8["distributed"]["rccl_ranks"] == 8 and c8["distributed"]["device_indices"] == list(range(8))
     assert set(c8["distributed"]["gather_modes"]) == {"p2p copy engines", "p2p direct stores", "rccl gather"}
     assert c8["roofline"]["frac"] == full["roofline"]["frac"] and c8["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    # round 6's line, from round 6's own full result: SURVEY 8(d)'s formula under its own name beside the measured HBM fraction,
+    # config 5's keys say which topology they are, the trainer's forest has a bound, the library's build id, split steps at N > 1
+    with open(os.path.join(ROOT, "profiles", "r06_bench.json")) as f:
+        full6 = json.load(f)
+    c6 = bench.compact_line(full6, "x.json")
+    assert len(json.dumps(c6)) < LINE_LIMIT
+    _check_contract(c6)
+    assert c6["roofline"]["survey_8d_frac"] == full6["roofline"]["algorithmic"]["over_hbm_peak"] > 1 > c6["roofline"]["hbm_frac"]
+    assert "algorithmic_over_hbm_peak" not in c6["roofline"]
+    assert c6["cfg5_full_mpix"] == full6["cfg5_shard"]["value"] and c6["cfg5_full_hbm_frac"] < c6["cfg5_balanced_hbm_frac"]
+    assert not any(k.startswith("cfg5_") and not k.startswith(("cfg5_full_", "cfg5_balanced_")) for k in c6)
+    assert c6["trainer_forest_bound"] == full6["cfg2_trainer_forest"]["roofline"]["bound"] and 0 < c6["trainer_forest_frac"] < 1
+    assert len(c6["config"]["library_build_id"]) == 16
+    full6["n_gpus"] = 8
+    full6["distributed"] = dict(full["distributed"])
+    full6["distributed"]["gather_modes"] = {"rccl gather": {"ms_per_step": 4.0, "value": 1e5, "cus_left_to_rccl": 32, "gather_check": "ok",
+                                                            "split_step_helper_workgroups": 96}}
+    c68 = bench.compact_line(full6, "x.json")
+    assert len(json.dumps(c68)) < LINE_LIMIT and c68["distributed"]["gather_modes"]["rccl gather"]["split_step_helper_workgroups"] == 96
