@@ -167,6 +167,30 @@ def test_two_ranks_with_split_steps(tmp_path):
 
 
 @pytest.mark.gpu
+def test_wall_time_guard_keeps_the_rccl_figure_and_names_what_it_skipped(tmp_path):
+    """Round 6: the N>1 default times the RCCL gather -- `value` -- FIRST and always; with the wall-time budget spent (here: a
+    budget of zero seconds) the transports beside it and config 5 on all ranks are skipped on every rank alike (rank 0's clock,
+    one broadcast per decision) and named in distributed.unavailable; the run still exits 0 with a verified line."""
+    env = dict(os.environ, RDF_BENCH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", "6", "--depth", "12", "--backend", "gloo", "--gather", "auto", "--reserve-cus", "0", "--time-budget", "0",
+           "--cfg5-frames", "2", "--cfg5-trees", "3", "--cfg5-depth", "12", "--full-json", str(tmp_path / "full.json")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = _last_json(r.stdout)
+    _check_contract(c)
+    assert c["n_gpus"] == 2 and c["config"]["gather"] == "rccl gather" and c["config"]["gather_check"] == "ok" and c["value"] > 0
+    d = _full(c, tmp_path / "full.json")
+    dd = d["distributed"]
+    assert list(dd["gather_modes"]) == ["rccl gather"] and dd["gather_modes"]["rccl gather"]["gather_check"] == "ok"
+    skipped = dd["unavailable"]
+    assert set(skipped) == {"p2p copy engines", "p2p direct stores", "cfg5_all_ranks"}, skipped
+    assert all("wall-time budget" in v for v in skipped.values())
+    assert "cfg5_all_ranks" not in d
+
+
+@pytest.mark.gpu
 def test_four_ranks_on_one_gpu(tmp_path):
     """The same rehearsal with four ranks (rank-indexed buffers, checksums and the config-5 leg beyond world size 2; four
     processes on the card stay inside the box's limit of six)."""
