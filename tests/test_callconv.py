@@ -185,6 +185,12 @@ def test_reference_app_constructor_runs_on_the_swapped_modules(rdf, host_runtime
     before = {n: sys.modules.get(n) for n in rdf._REFERENCE_MODULE_NAMES}
     try:
         assert rdf.install_reference_aliases() == list(rdf._REFERENCE_MODULE_NAMES)
+        assert rdf.install_reference_aliases() == list(rdf._REFERENCE_MODULE_NAMES)        # (twice is harmless)
+        import types
+        sys.modules["util"] = types.ModuleType("util")          # somebody else's module of that name: refused unless forced
+        with pytest.raises(ImportError, match="already imported"):
+            rdf.install_reference_aliases()
+        assert "util" in rdf.install_reference_aliases(force=True)
         ns = {}
         exec("from decision_tree import *\n"                      # run_live_layered.py:6
              "from cuda.points_ops import *\n"                    # :7

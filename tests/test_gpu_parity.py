@@ -1810,6 +1810,15 @@ def test_split_launch_shares_one_tile_queue(rdf, oracle, gpu_runtime):
         torch.cuda.synchronize()
         got = out_f.get()
         assert rc == 0 and np.array_equal(got, want_f), (rc, n_h.value, int((got != want_f).sum()))
+        # without the dynamic tile queue (static striding, one workgroup per tile) there is nothing to share: one ordinary launch
+        for mode in (0, 2):
+            lib.rdf_set_scheduler(mode)
+            out = outs[2].fill(65535)
+            with torch.cuda.stream(main):
+                assert ev.get_labels_forest_split(f, depth, out, helper.cuda_stream, 32) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(out.get(), want), mode
+        lib.rdf_set_scheduler(-1)
         # helper_cus 0, or the same stream twice: one ordinary launch
         for hs, cus in ((helper.cuda_stream, 0), (main.cuda_stream, 32)):
             out = outs[1].fill(65535)
@@ -1819,6 +1828,7 @@ def test_split_launch_shares_one_tile_queue(rdf, oracle, gpu_runtime):
             assert np.array_equal(out.get(), want)
     finally:
         torch.cuda.synchronize()
+        lib.rdf_set_scheduler(-1)
         lib.rdf_stream_destroy(h)
 
 
