@@ -414,7 +414,8 @@ class DecisionTreeEvaluator:
         """get_labels_forest as TWO launches that share one tile queue (rdf_eval_forest_packed_split): a main launch on the
         current stream -- meant to be a CU-masked one (rdf_stream_create_with_reserved_cus) -- and a helper launch on
         `helper_stream` (a raw hipStream_t handle) that the caller has made wait for whatever occupies the `helper_cus` compute
-        units the main stream leaves alone: a multi-GPU step's RCCL gather (distributed.ShardedForestEvaluator).  Packed forests,
+        units the main stream leaves alone: a multi-GPU step's RCCL gather (distributed.ShardedForestEvaluator) -- and for
+        whatever wrote the frames and pre-filled `labels_out` (`helper.wait_stream(current)`); readers wait for both streams.  Packed forests,
         one C-ABI call (< 2^31 pixels).  Returns the helper launch's workgroups (0: the launch was not split).  Not in the
         reference (single-GPU)."""
         import ctypes

@@ -244,6 +244,9 @@ int rdf_eval_forest_packed_filled(const uint16_t *depth, int n_img, int dim_x, i
  * the caller makes `helper_stream` (an ordinary stream) wait for the previous step's gather before this call: the helper's
  * workgroups then start on the units the gather has just left and pull tiles from the same queue until it is empty, however
  * early or late they arrive (a helper that arrives after the main launch has finished finds the queue empty and retires).
+ * Both streams are the caller's to order: `helper_stream` must ALSO come after whatever wrote `depth`, `filter` and the
+ * pre-fill of `labels_out` (a helper that runs ahead of a fill sees its labels overwritten), and whoever reads `labels_out`
+ * must wait for both streams.
  *   helper_cus    compute units the helper may count on (its grid is this many times the workgroups one unit holds); 0: one
  *                 ordinary launch
  *   queue_tag     0..3: which of `stream`'s split queue slots the two launches share.  A slot must not be used by a later

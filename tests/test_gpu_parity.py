@@ -1790,12 +1790,15 @@ def test_split_launch_shares_one_tile_queue(rdf, oracle, gpu_runtime):
             ev.get_labels_forest(f, depth, out)
         torch.cuda.synchronize()
         assert np.array_equal(out.get(), want)
-        # one frame: no more tiles than the main launch has workgroups -- not split, the helper stream is not touched
+        # one frame (a small launch: 256-thread workgroups, narrow tiles; 1 590 tiles on the masked stream's 1 120 slots, so it is
+        # split too).  The helper stream is the CALLER's to order: it must come after whatever wrote the inputs and the pre-fill
+        # (here: the fill, on the current stream) -- a helper that ran ahead of the fill would see its labels overwritten
         one = rdf.DeviceArray((1,) + depth_np.shape[1:], np.uint16).fill(65535)
         with torch.cuda.stream(main):
+            helper.wait_stream(main)
             n = ev.get_labels_forest_split(f, depth[3:4], one, helper.cuda_stream, 32)
         torch.cuda.synchronize()
-        assert np.array_equal(one.get(), want[3:4])
+        assert n > 0 and np.array_equal(one.get(), want[3:4])
         # a filtered launch through the C entry point (pixel lists; at labels_reduce 2 such a launch takes 512-thread workgroups)
         lh, lw = 480 // 2, 848 // 2
         filt_np = (np.arange(24 * lh * lw).reshape(24, lh, lw) % 3).astype(np.uint16)
@@ -1805,6 +1808,7 @@ def test_split_launch_shares_one_tile_queue(rdf, oracle, gpu_runtime):
         out_f = rdf.DeviceArray((24, lh, lw), np.uint16).fill(0)
         n_h = ctypes.c_int(0)
         with torch.cuda.stream(main):
+            helper.wait_stream(main)            # (the fill above)
             rc = lib.rdf_eval_forest_packed_split(depth.ptr, 24, 848, 480, f.packed(1.0).ptr, f.forest_cu.ptr, 4, 12, 4, filt.ptr, 1, out_f.ptr, 2, 1,
                                                   ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(helper.cuda_stream), 32, 1, ctypes.byref(n_h))
         torch.cuda.synchronize()
