@@ -47,3 +47,16 @@ def test_the_rounds_profiles_describe_the_shipped_code():
             if f.endswith((".hip", ".hpp", ".py", ".h")):
                 assert "RDF_EXPERIMENT" not in open(os.path.join(dirpath, f)).read(), f
     assert "RDF_EXPERIMENT" not in open(os.path.join(ROOT, "include", "rdf_hip.h")).read()
+
+
+def test_the_rounds_experiment_script_still_applies_to_the_sources():
+    """profiles/r06_headline_ablation.txt was produced by variants that tools/make_exp_r06.py derives from a COPY of the product
+    sources: its edits must still find their anchors in today's sources (no build here), and must leave the product untouched."""
+    spec = importlib.util.spec_from_file_location("make_exp_r06", os.path.join(ROOT, "tools", "make_exp_r06.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    before = open(os.path.join(ROOT, "3d-beats_amd", "csrc", "rdf_hip.hip")).read()
+    m.edit()
+    assert open(os.path.join(ROOT, "3d-beats_amd", "csrc", "rdf_hip.hip")).read() == before
+    edited = open(os.path.join(m.SRC, "rdf_hip.hip")).read()
+    assert "RDF_ABL_PDF" in edited and "RDF_ABL_LDSNODES" in edited and "BLOCK == 896 ? 7" in edited and "RDF_ABL" not in before
